@@ -1,0 +1,88 @@
+"""ctypes binding of libfdtd2d.so (include/fdtd2d.h).
+
+This is the whole FFI: plain pointers and sizes, no torch types.  The library is
+built in-tree by ``__graft_entry__.build()`` / ``fdtd-2d_amd/csrc/Makefile`` and is
+required: there is no CPU fallback, a missing library or device raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libfdtd2d.so")
+
+F32, F64 = 0, 1
+BOUNDARY_NONE, BOUNDARY_MUR5, BOUNDARY_PML = 0, 1, 2
+SRC_NONE, SRC_RICKER, SRC_SINUSOIDAL = 0, 1, 2
+FIELD_EZ, FIELD_HX, FIELD_HY = 0, 1, 2
+
+E_ARG, E_NODEVICE, E_NOMEM, E_STATE, E_COURANT = -1, -2, -3, -4, -5
+
+(INFO_ROWS, INFO_COLS, INFO_ROW0, INFO_NROWS, INFO_HALO, INFO_PITCH, INFO_DTYPE,
+ INFO_BOUNDARY, INFO_DEVICE, INFO_EPS_UNIFORM, INFO_MU_UNIFORM, INFO_E_VALID_LO,
+ INFO_E_VALID_HI, INFO_H_VALID_LO, INFO_H_VALID_HI, INFO_STEP) = range(16)
+
+_vp, _i, _d, _ll = C.c_void_p, C.c_int, C.c_double, C.c_longlong
+
+# name -> (restype, argtypes); every symbol include/fdtd2d.h declares
+SIGNATURES = {
+    "fdtd2d_create": (_i, [C.POINTER(_vp), _i, _i, _d, _d, _i, _i, _i]),
+    "fdtd2d_create_slab": (_i, [C.POINTER(_vp), _i, _i, _i, _i, _i, _d, _d, _i, _i, _i]),
+    "fdtd2d_destroy": (None, [_vp]),
+    "fdtd2d_last_error": (C.c_char_p, [_vp]),
+    "fdtd2d_info": (_ll, [_vp, _i]),
+    "fdtd2d_set_stream": (_i, [_vp, _vp]),
+    "fdtd2d_set_materials": (_i, [_vp, _vp, _vp, _i, C.POINTER(_d), _i]),
+    "fdtd2d_set_materials_uniform": (_i, [_vp, _d, _d]),
+    "fdtd2d_courant": (_d, [_vp]),
+    "fdtd2d_upload": (_i, [_vp, _vp, _vp, _vp, _i]),
+    "fdtd2d_download": (_i, [_vp, _vp, _vp, _vp, _i]),
+    "fdtd2d_reset": (_i, [_vp]),
+    "fdtd2d_update_h": (_i, [_vp]),
+    "fdtd2d_update_e": (_i, [_vp]),
+    "fdtd2d_add_point": (_i, [_vp, _i, _i, _d]),
+    "fdtd2d_run": (_i, [_vp, _i, _i, _i, C.POINTER(_d)]),
+    "fdtd2d_run_waveform": (_i, [_vp, _i, _i, _i, _i, _d, _ll]),
+    "fdtd2d_source_amplitude": (_d, [_i, _d, _d]),
+    "fdtd2d_sync": (_i, [_vp]),
+    "fdtd2d_halo_bytes": (_ll, [_vp]),
+    "fdtd2d_halo_pack": (_i, [_vp, _i, _vp]),
+    "fdtd2d_halo_unpack": (_i, [_vp, _i, _vp]),
+    "fdtd2d_timer_start": (_i, [_vp]),
+    "fdtd2d_timer_stop": (_i, [_vp, C.POINTER(C.c_float)]),
+    "fdtd2d_bytes_per_cell_step": (_i, [_vp]),
+    "fdtd2d_device_ptr": (_vp, [_vp, _i]),
+    "fdtd2d_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+class Fdtd2dError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libfdtd2d error {code}: {msg}")
+        self.code = code
+
+
+def load():
+    """Load libfdtd2d.so and declare every prototype.  Raises if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (or `make -C fdtd-2d_amd/csrc`). There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(handle, rc: int):
+    if rc != 0:
+        msg = load().fdtd2d_last_error(handle)
+        raise Fdtd2dError(rc, msg.decode() if msg else "")
+    return rc

@@ -1,0 +1,803 @@
+// libfdtd2d.so -- host side of the C ABI declared in include/fdtd2d.h.
+// MI355X (gfx950) only.  No CPU fallback: every compute entry point needs the device.
+#include "../../include/fdtd2d.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels_step.hpp"
+
+using fdtd::Geom;
+
+namespace {
+
+thread_local std::string g_create_error = "";
+
+struct Range {
+    int lo, hi;
+};
+
+}  // namespace
+
+struct fdtd2d {
+    int rows = 0, cols = 0;      // global grid
+    int row0 = 0, nrows = 0;     // owned rows
+    int halo = 0;                // halo rows kept on each side (storage is symmetric)
+    int dtype = FDTD2D_F32, boundary = FDTD2D_BOUNDARY_MUR5, device = 0;
+    double dt = 0, dx = 0;
+    long long pitch = 0;         // elements per stored row
+    int stored = 0;              // stored rows = nrows + 2*halo
+    size_t esz = 4;              // element size
+    size_t field_bytes = 0;      // bytes of one stored field (without guard)
+
+    void *ez[2] = {nullptr, nullptr};
+    int cur = 0;                 // ez[cur] is the current Ez
+    void *hx = nullptr, *hy = nullptr;
+    void *ce = nullptr, *ch = nullptr;    // coefficient arrays (nullptr when uniform)
+    bool have_mat = false, ce_uniform = true, ch_uniform = true;
+    double ce_u = 0, ch_u = 0;   // uniform coefficients, already rounded to T
+    double k_mur = 0;            // Mur factor, already rounded to T
+    double eps_min = 0, mu_min = 0;
+
+    Range ev{0, 0}, hv{0, 0};    // global rows on which Ez / (Hx,Hy) are current
+    long long step = 0;
+
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    std::string err;
+
+    bool top() const { return row0 == 0; }
+    bool bottom() const { return row0 + nrows == rows; }
+    int row_base() const { return row0 - halo; }
+    int store_lo() const { return std::max(0, row0 - halo); }
+    int store_hi() const { return std::min(rows, row0 + nrows + halo); }
+    Geom geom() const { return Geom{rows, cols, row_base(), pitch}; }
+};
+
+namespace {
+
+int fail(fdtd2d *h, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf;
+    else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(h, expr)                                                                        \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail((h), -(1000 + (int)e_), "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+int use_device(fdtd2d *h)
+{
+    hipError_t e = hipSetDevice(h->device);
+    if (e != hipSuccess)
+        return fail(h, FDTD2D_E_NODEVICE, "hipSetDevice(%d): %s", h->device, hipGetErrorString(e));
+    return 0;
+}
+
+template <class T> T round_to(double x) { return (T)x; }
+
+// dt/(x*dx) in T, as main.py:27,70,74 evaluate it for arrays of type T
+template <class T> double coef_of(double x, double dt, double dx)
+{
+    const T xt = (T)x, dtt = (T)dt, dxt = (T)dx;
+    volatile T prod = xt * dxt;
+    volatile T q = dtt / prod;
+    return (double)q;
+}
+
+// (c*dt - dx)/(c*dt + dx), c = 1/sqrt(mu00*eps00), every operation in T (main.py:30-31)
+template <class T> double mur_of(double eps00, double mu00, double dt, double dx)
+{
+    const T e = (T)eps00, m = (T)mu00, dtt = (T)dt, dxt = (T)dx;
+    volatile T prod = m * e;
+    volatile T s = std::sqrt((T)prod);
+    volatile T c = (T)1 / s;
+    volatile T cdt = c * dtt;
+    volatile T num = cdt - dxt, den = cdt + dxt;
+    volatile T k = num / den;
+    return (double)k;
+}
+
+double get_elem(const void *p, int dt, size_t i)
+{
+    return dt == FDTD2D_F64 ? ((const double *)p)[i] : (double)((const float *)p)[i];
+}
+
+// Copy host rows (host_cols elements each, of host_dtype) into device rows starting at
+// stored row `srow`, converting to the engine's type when they differ.
+int copy_in(fdtd2d *h, void *dev, const void *host, int host_dtype, int srow, int nrows,
+            int host_cols)
+{
+    if (nrows <= 0) return 0;
+    char *d = (char *)dev + (size_t)srow * h->pitch * h->esz;
+    if (host_dtype == h->dtype) {
+        HIPCHK(h, hipMemcpy2D(d, h->pitch * h->esz, host, (size_t)host_cols * h->esz,
+                              (size_t)host_cols * h->esz, nrows, hipMemcpyHostToDevice));
+        return 0;
+    }
+    const int chunk = std::max(1, (int)((64u << 20) / ((size_t)host_cols * h->esz)));
+    std::vector<char> tmp((size_t)std::min(chunk, nrows) * host_cols * h->esz);
+    for (int r = 0; r < nrows; r += chunk) {
+        const int n = std::min(chunk, nrows - r);
+        const size_t cnt = (size_t)n * host_cols, off = (size_t)r * host_cols;
+        if (h->dtype == FDTD2D_F32) {
+            float *t = (float *)tmp.data();
+            const double *s = (const double *)host + off;
+            for (size_t i = 0; i < cnt; ++i) t[i] = (float)s[i];
+        } else {
+            double *t = (double *)tmp.data();
+            const float *s = (const float *)host + off;
+            for (size_t i = 0; i < cnt; ++i) t[i] = (double)s[i];
+        }
+        HIPCHK(h, hipMemcpy2D(d + (size_t)r * h->pitch * h->esz, h->pitch * h->esz, tmp.data(),
+                              (size_t)host_cols * h->esz, (size_t)host_cols * h->esz, n,
+                              hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+int copy_out(fdtd2d *h, const void *dev, void *host, int host_dtype, int srow, int nrows,
+             int host_cols)
+{
+    if (nrows <= 0) return 0;
+    const char *d = (const char *)dev + (size_t)srow * h->pitch * h->esz;
+    if (host_dtype == h->dtype) {
+        HIPCHK(h, hipMemcpy2D(host, (size_t)host_cols * h->esz, d, h->pitch * h->esz,
+                              (size_t)host_cols * h->esz, nrows, hipMemcpyDeviceToHost));
+        return 0;
+    }
+    const int chunk = std::max(1, (int)((64u << 20) / ((size_t)host_cols * h->esz)));
+    std::vector<char> tmp((size_t)std::min(chunk, nrows) * host_cols * h->esz);
+    for (int r = 0; r < nrows; r += chunk) {
+        const int n = std::min(chunk, nrows - r);
+        const size_t cnt = (size_t)n * host_cols, off = (size_t)r * host_cols;
+        HIPCHK(h, hipMemcpy2D(tmp.data(), (size_t)host_cols * h->esz,
+                              d + (size_t)r * h->pitch * h->esz, h->pitch * h->esz,
+                              (size_t)host_cols * h->esz, n, hipMemcpyDeviceToHost));
+        if (h->dtype == FDTD2D_F32) {
+            const float *t = (const float *)tmp.data();
+            double *s = (double *)host + off;
+            for (size_t i = 0; i < cnt; ++i) s[i] = (double)t[i];
+        } else {
+            const double *t = (const double *)tmp.data();
+            float *s = (float *)host + off;
+            for (size_t i = 0; i < cnt; ++i) s[i] = (float)t[i];
+        }
+    }
+    return 0;
+}
+
+int zero_fields(fdtd2d *h)
+{
+    for (void *p : {h->ez[0], h->ez[1], h->hx, h->hy})
+        HIPCHK(h, hipMemsetAsync(p, 0, h->field_bytes + 256, h->stream));
+    h->cur = 0;
+    h->ev = h->hv = Range{h->store_lo(), h->store_hi()};
+    h->step = 0;
+    return 0;
+}
+
+// ---- launches --------------------------------------------------------------------------
+
+template <class T> int launch_h(fdtd2d *h, int lo, int hi)
+{
+    if (hi <= lo) return 0;
+    constexpr int V = fdtd::Vec<T>::N, RPT = 4;
+    const Geom g = h->geom();
+    dim3 block(64, 4);
+    dim3 grid((unsigned)((h->cols - 1 + 64 * V - 1) / (64 * V)),
+              (unsigned)((hi - lo + 4 * RPT - 1) / (4 * RPT)));
+    const T *ez = (const T *)h->ez[h->cur];
+    if (h->ch_uniform)
+        hipLaunchKernelGGL((fdtd::k_update_h<T, false, RPT>), grid, block, 0, h->stream, ez,
+                           (T *)h->hx, (T *)h->hy, (const T *)nullptr, (T)h->ch_u, g, lo, hi);
+    else
+        hipLaunchKernelGGL((fdtd::k_update_h<T, true, RPT>), grid, block, 0, h->stream, ez,
+                           (T *)h->hx, (T *)h->hy, (const T *)h->ch, (T)0, g, lo, hi);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+template <class T, bool CE_ARR> int launch_e_impl(fdtd2d *h, int lo, int hi)
+{
+    constexpr int V = fdtd::Vec<T>::N, RPT = 4;
+    const Geom g = h->geom();
+    const T *ez_old = (const T *)h->ez[h->cur];
+    T *ez_new = (T *)h->ez[h->cur ^ 1];
+    const T *ce = CE_ARR ? (const T *)h->ce : (const T *)nullptr;
+    const T ce_u = CE_ARR ? (T)0 : (T)h->ce_u;
+    dim3 block(64, 4);
+    dim3 grid((unsigned)((h->cols + 64 * V - 1) / (64 * V)),
+              (unsigned)((hi - lo + 4 * RPT - 1) / (4 * RPT)));
+    hipLaunchKernelGGL((fdtd::k_update_e<T, CE_ARR, RPT>), grid, block, 0, h->stream, ez_old,
+                       ez_new, (const T *)h->hx, (const T *)h->hy, ce, ce_u, g, lo, hi);
+    HIPCHK(h, hipGetLastError());
+    if (h->boundary == FDTD2D_BOUNDARY_MUR5) {
+        const int has_top = lo == 0, has_bot = hi == h->rows;
+        const int vlo = has_top ? std::max(lo, 5) : lo;
+        const int vhi = has_bot ? std::min(hi, h->rows - 5) : hi;
+        long long n = (vhi > vlo ? (long long)(vhi - vlo) * 16 : 0) +
+                      (long long)(has_top + has_bot) * 5 * h->cols;
+        if (n > 0) {
+            fdtd::FrameCtx<T, CE_ARR> f{ez_old, (const T *)h->hx, (const T *)h->hy, ce, ce_u,
+                                        (T)h->k_mur, g};
+            hipLaunchKernelGGL((fdtd::k_frame_mur<T, CE_ARR>), dim3((unsigned)((n + 255) / 256)),
+                               dim3(256), 0, h->stream, f, ez_new, lo, hi, has_top, has_bot);
+            HIPCHK(h, hipGetLastError());
+        }
+    }
+    h->cur ^= 1;
+    return 0;
+}
+
+template <class T> int launch_e(fdtd2d *h, int lo, int hi)
+{
+    if (hi <= lo) return 0;
+    return h->ce_uniform ? launch_e_impl<T, false>(h, lo, hi) : launch_e_impl<T, true>(h, lo, hi);
+}
+
+template <class T> int launch_point(fdtd2d *h, int row, int col, double amp)
+{
+    const Geom g = h->geom();
+    hipLaunchKernelGGL((fdtd::k_add_point<T>), dim3(1), dim3(1), 0, h->stream,
+                       (T *)h->ez[h->cur], fdtd::at(g, row, col), amp);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+int need_ready(fdtd2d *h)
+{
+    if (!h) return FDTD2D_E_ARG;
+    if (!h->have_mat)
+        return fail(h, FDTD2D_E_STATE, "materials not set: call fdtd2d_set_materials first");
+    return use_device(h);
+}
+
+int do_update_h(fdtd2d *h)
+{
+    // Hx[i] needs Ez[i], Ez[i+1] (main.py:69-70): the H range shrinks to where both are current
+    const int lo = std::max(h->hv.lo, h->ev.lo);
+    const int hi = std::min(h->hv.hi, h->ev.hi == h->rows ? h->rows : h->ev.hi - 1);
+    if (hi <= lo) return fail(h, FDTD2D_E_STATE, "no rows with current Ez left: refresh the halo");
+    const int khi = std::min(hi, h->rows - 1);   // row R-1 of Hx/Hy is never updated
+    int rc = h->dtype == FDTD2D_F32 ? launch_h<float>(h, lo, khi) : launch_h<double>(h, lo, khi);
+    if (rc) return rc;
+    h->hv = Range{lo, hi};
+    return 0;
+}
+
+int do_update_e(fdtd2d *h)
+{
+    // Ez[i] needs Hx[i-1], Hx[i], Hy[i] (main.py:21-27)
+    const int lo = std::max(h->ev.lo, h->hv.lo == 0 ? 0 : h->hv.lo + 1);
+    const int hi = std::min(h->ev.hi, h->hv.hi);
+    if (hi <= lo) return fail(h, FDTD2D_E_STATE, "no rows with current H left: refresh the halo");
+    if (h->boundary == FDTD2D_BOUNDARY_MUR5) {
+        // the horizontal bands need rows 0..5 / R-6..R-1 together
+        if ((lo > 0 && lo < 6) || (hi < h->rows && hi > h->rows - 6))
+            return fail(h, FDTD2D_E_STATE, "current rows [%d,%d) cut through the Mur band", lo, hi);
+    }
+    int rc = h->dtype == FDTD2D_F32 ? launch_e<float>(h, lo, hi) : launch_e<double>(h, lo, hi);
+    if (rc) return rc;
+    h->ev = Range{lo, hi};
+    h->step++;
+    return 0;
+}
+
+int do_add_point(fdtd2d *h, int row, int col, double amp)
+{
+    if (row < 0 || row >= h->rows || col < 0 || col >= h->cols)
+        return fail(h, FDTD2D_E_ARG, "source cell (%d,%d) outside the %dx%d grid", row, col,
+                    h->rows, h->cols);
+    if (row < h->ev.lo || row >= h->ev.hi) return 0;   // not on this slab's current rows
+    return h->dtype == FDTD2D_F32 ? launch_point<float>(h, row, col, amp)
+                                  : launch_point<double>(h, row, col, amp);
+}
+
+template <class T> int make_coef(fdtd2d *h, void *arr)
+{
+    const size_t n = (size_t)h->stored * h->pitch;
+    hipLaunchKernelGGL((fdtd::k_coef<T>), dim3(2048), dim3(256), 0, h->stream, (T *)arr, n,
+                       (T)h->dt, (T)h->dx);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+// scan a host array: min value, and whether all elements (after rounding to T) are equal
+template <class T>
+void scan_host(const void *p, int host_dtype, size_t n, double *mn, bool *uniform, double *first)
+{
+    double m = get_elem(p, host_dtype, 0);
+    const T f = (T)m;
+    bool u = true;
+    if (host_dtype == FDTD2D_F64) {
+        const double *s = (const double *)p;
+        for (size_t i = 0; i < n; ++i) {
+            m = std::min(m, s[i]);
+            u = u && ((T)s[i] == f);
+        }
+    } else {
+        const float *s = (const float *)p;
+        for (size_t i = 0; i < n; ++i) {
+            m = std::min(m, (double)s[i]);
+            u = u && ((T)s[i] == f);
+        }
+    }
+    *mn = m;
+    *uniform = u;
+    *first = (double)f;
+}
+
+int create_impl(fdtd2d_t **out, int rows, int cols, int row0, int nrows, int halo, double dt,
+                double dx, int dtype, int boundary, int device)
+{
+    if (!out) return fail(nullptr, FDTD2D_E_ARG, "out is NULL");
+    *out = nullptr;
+    if (rows < 11 || cols < 11)
+        return fail(nullptr, FDTD2D_E_ARG,
+                    "grid %dx%d is below the 11x11 minimum of the 5-px Mur band", rows, cols);
+    if (dtype != FDTD2D_F32 && dtype != FDTD2D_F64)
+        return fail(nullptr, FDTD2D_E_ARG, "dtype must be FDTD2D_F32 or FDTD2D_F64");
+    if (boundary != FDTD2D_BOUNDARY_NONE && boundary != FDTD2D_BOUNDARY_MUR5)
+        return fail(nullptr, FDTD2D_E_ARG, "boundary %d is not available in this build", boundary);
+    if (!(dt > 0) || !(dx > 0)) return fail(nullptr, FDTD2D_E_ARG, "dt and dx must be positive");
+    if (row0 < 0 || nrows <= 0 || row0 + nrows > rows || halo < 0)
+        return fail(nullptr, FDTD2D_E_ARG, "slab [%d,%d) does not fit a %d-row grid", row0,
+                    row0 + nrows, rows);
+    const bool whole = (row0 == 0 && nrows == rows);
+    if (!whole) {
+        if (halo < 1) return fail(nullptr, FDTD2D_E_ARG, "a slab with neighbours needs halo >= 1");
+        // the horizontal Mur bands (6 rows deep incl. their inputs) must sit inside one slab,
+        // and a neighbour's halo must not reach into them
+        if ((row0 > 0 && row0 - halo < 6) || (row0 + nrows < rows && row0 + nrows + halo > rows - 6))
+            return fail(nullptr, FDTD2D_E_ARG,
+                        "slab [%d,%d) with halo %d reaches into the 6-row boundary band of a "
+                        "neighbouring slab", row0, row0 + nrows, halo);
+    }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, FDTD2D_E_NODEVICE,
+                    "no HIP device available (%s); libfdtd2d has no CPU path",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (device < 0 || device >= ndev)
+        return fail(nullptr, FDTD2D_E_ARG, "device %d out of range (%d visible)", device, ndev);
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess)
+        return fail(nullptr, FDTD2D_E_NODEVICE, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, FDTD2D_E_NODEVICE, "device %d is %s; this library is built for gfx950",
+                    device, prop.gcnArchName);
+
+    fdtd2d *h = new fdtd2d();
+    h->rows = rows; h->cols = cols; h->row0 = row0; h->nrows = nrows;
+    h->halo = whole ? 0 : halo;
+    h->dt = dt; h->dx = dx; h->dtype = dtype; h->boundary = boundary; h->device = device;
+    h->esz = dtype == FDTD2D_F32 ? 4 : 8;
+    h->pitch = ((long long)cols + 63) / 64 * 64;
+    h->stored = nrows + 2 * h->halo;
+    h->field_bytes = (size_t)h->stored * h->pitch * h->esz;
+    int rc = use_device(h);
+    auto bail = [&](int code) {
+        g_create_error = h->err;
+        fdtd2d_destroy(h);
+        return code;
+    };
+    if (rc) return bail(rc);
+    if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess)
+        return bail(fail(h, FDTD2D_E_NODEVICE, "hipStreamCreate failed"));
+    h->stream = h->own_stream;
+    if (hipEventCreate(&h->t0) != hipSuccess || hipEventCreate(&h->t1) != hipSuccess)
+        return bail(fail(h, FDTD2D_E_NODEVICE, "hipEventCreate failed"));
+    for (void **p : {&h->ez[0], &h->ez[1], &h->hx, &h->hy}) {
+        // +256 B guard: the last lane of a row may look one vector past the row end
+        if (hipMalloc(p, h->field_bytes + 256) != hipSuccess)
+            return bail(fail(h, FDTD2D_E_NOMEM, "hipMalloc of %zu bytes failed", h->field_bytes));
+    }
+    rc = zero_fields(h);
+    if (rc) return bail(rc);
+    if (hipStreamSynchronize(h->stream) != hipSuccess)
+        return bail(fail(h, FDTD2D_E_NODEVICE, "device sync failed after allocation"));
+    *out = h;
+    return 0;
+}
+
+template <class T>
+int set_materials_impl(fdtd2d *h, const void *eps, const void *mu, int host_dtype,
+                       const double *corner, int allow_uniform)
+{
+    const int slo = h->store_lo(), shi = h->store_hi();
+    const size_t n = (size_t)(shi - slo) * h->cols;
+    double emin, mmin, e0, m0;
+    bool eu, mu_u;
+    scan_host<T>(eps, host_dtype, n, &emin, &eu, &e0);
+    scan_host<T>(mu, host_dtype, n, &mmin, &mu_u, &m0);
+    if (!(emin > 0) || !(mmin > 0)) return fail(h, FDTD2D_E_ARG, "eps and mu must be positive");
+    double eps00, mu00;
+    if (corner) {
+        eps00 = corner[0];
+        mu00 = corner[1];
+    } else if (slo == 0) {
+        eps00 = get_elem(eps, host_dtype, 0);
+        mu00 = get_elem(mu, host_dtype, 0);
+    } else {
+        return fail(h, FDTD2D_E_ARG, "corner {eps[0,0], mu[0,0]} is required for a slab that does "
+                                     "not store global row 0");
+    }
+    h->eps_min = emin;
+    h->mu_min = mmin;
+    h->k_mur = mur_of<T>(eps00, mu00, h->dt, h->dx);
+    h->ce_uniform = eu && allow_uniform;
+    h->ch_uniform = mu_u && allow_uniform;
+    auto setup = [&](bool uniform, void **arr, const void *host, double first, double *cu) -> int {
+        if (uniform) {
+            if (*arr) { (void)hipFree(*arr); *arr = nullptr; }
+            *cu = coef_of<T>(first, h->dt, h->dx);
+            return 0;
+        }
+        if (!*arr) {
+            if (hipMalloc(arr, h->field_bytes + 256) != hipSuccess)
+                return fail(h, FDTD2D_E_NOMEM, "hipMalloc of a coefficient array failed");
+        }
+        HIPCHK(h, hipMemsetAsync(*arr, 0, h->field_bytes + 256, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        int rc = copy_in(h, *arr, host, host_dtype, slo - h->row_base(), shi - slo, h->cols);
+        if (rc) return rc;
+        return make_coef<T>(h, *arr);
+    };
+    int rc = setup(h->ce_uniform, &h->ce, eps, e0, &h->ce_u);
+    if (rc) return rc;
+    rc = setup(h->ch_uniform, &h->ch, mu, m0, &h->ch_u);
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->have_mat = true;
+    return 0;
+}
+
+int halo_rows(fdtd2d *h, int side, bool pack, int *first)
+{
+    if (side != 0 && side != 1) return fail(h, FDTD2D_E_ARG, "side must be 0 (top) or 1 (bottom)");
+    if (h->halo == 0) return fail(h, FDTD2D_E_STATE, "this handle has no halo");
+    if ((side == 0 && h->top()) || (side == 1 && h->bottom()))
+        return fail(h, FDTD2D_E_STATE, "no neighbour on side %d", side);
+    if (pack) *first = side == 0 ? h->row0 : h->row0 + h->nrows - h->halo;
+    else *first = side == 0 ? h->row0 - h->halo : h->row0 + h->nrows;
+    return 0;
+}
+
+template <class T, bool PACK> int launch_halo(fdtd2d *h, int first, void *buf)
+{
+    const size_t n = (size_t)3 * h->halo * h->cols;
+    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL((fdtd::k_halo<T, PACK>), dim3(blocks), dim3(256), 0, h->stream,
+                       (T *)h->ez[h->cur], (T *)h->hx, (T *)h->hy, (T *)buf, h->geom(), first,
+                       h->halo);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+// ===================================== C ABI ============================================
+
+extern "C" {
+
+const char *fdtd2d_version(void) { return "fdtd2d-mi355x 0.1 (gfx950)"; }
+
+int fdtd2d_create(fdtd2d_t **out, int rows, int cols, double dt, double dx, int dtype,
+                  int boundary, int device)
+{
+    return create_impl(out, rows, cols, 0, rows, 0, dt, dx, dtype, boundary, device);
+}
+
+int fdtd2d_create_slab(fdtd2d_t **out, int rows, int cols, int row0, int nrows, int halo,
+                       double dt, double dx, int dtype, int boundary, int device)
+{
+    return create_impl(out, rows, cols, row0, nrows, halo, dt, dx, dtype, boundary, device);
+}
+
+void fdtd2d_destroy(fdtd2d_t *h)
+{
+    if (!h) return;
+    if (hipSetDevice(h->device) == hipSuccess) {
+        if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
+        for (void *p : {h->ez[0], h->ez[1], h->hx, h->hy, h->ce, h->ch})
+            if (p) (void)hipFree(p);
+        if (h->t0) (void)hipEventDestroy(h->t0);
+        if (h->t1) (void)hipEventDestroy(h->t1);
+        if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    }
+    delete h;
+}
+
+const char *fdtd2d_last_error(const fdtd2d_t *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+long long fdtd2d_info(const fdtd2d_t *h, int what)
+{
+    if (!h) return FDTD2D_E_ARG;
+    switch (what) {
+    case FDTD2D_INFO_ROWS: return h->rows;
+    case FDTD2D_INFO_COLS: return h->cols;
+    case FDTD2D_INFO_ROW0: return h->row0;
+    case FDTD2D_INFO_NROWS: return h->nrows;
+    case FDTD2D_INFO_HALO: return h->halo;
+    case FDTD2D_INFO_PITCH: return h->pitch;
+    case FDTD2D_INFO_DTYPE: return h->dtype;
+    case FDTD2D_INFO_BOUNDARY: return h->boundary;
+    case FDTD2D_INFO_DEVICE: return h->device;
+    case FDTD2D_INFO_EPS_UNIFORM: return h->have_mat && h->ce_uniform;
+    case FDTD2D_INFO_MU_UNIFORM: return h->have_mat && h->ch_uniform;
+    case FDTD2D_INFO_E_VALID_LO: return h->ev.lo;
+    case FDTD2D_INFO_E_VALID_HI: return h->ev.hi;
+    case FDTD2D_INFO_H_VALID_LO: return h->hv.lo;
+    case FDTD2D_INFO_H_VALID_HI: return h->hv.hi;
+    case FDTD2D_INFO_STEP: return h->step;
+    default: return FDTD2D_E_ARG;
+    }
+}
+
+int fdtd2d_set_stream(fdtd2d_t *h, void *hip_stream)
+{
+    if (!h) return FDTD2D_E_ARG;
+    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    return 0;
+}
+
+int fdtd2d_set_materials(fdtd2d_t *h, const void *eps, const void *mu, int host_dtype,
+                         const double *corner, int allow_uniform)
+{
+    if (!h) return FDTD2D_E_ARG;
+    if (!eps || !mu) return fail(h, FDTD2D_E_ARG, "eps and mu must not be NULL");
+    if (host_dtype != FDTD2D_F32 && host_dtype != FDTD2D_F64)
+        return fail(h, FDTD2D_E_ARG, "bad host_dtype");
+    int rc = use_device(h);
+    if (rc) return rc;
+    return h->dtype == FDTD2D_F32
+               ? set_materials_impl<float>(h, eps, mu, host_dtype, corner, allow_uniform)
+               : set_materials_impl<double>(h, eps, mu, host_dtype, corner, allow_uniform);
+}
+
+int fdtd2d_set_materials_uniform(fdtd2d_t *h, double eps, double mu)
+{
+    if (!h) return FDTD2D_E_ARG;
+    if (!(eps > 0) || !(mu > 0)) return fail(h, FDTD2D_E_ARG, "eps and mu must be positive");
+    int rc = use_device(h);
+    if (rc) return rc;
+    for (void **p : {&h->ce, &h->ch})
+        if (*p) { (void)hipFree(*p); *p = nullptr; }
+    h->ce_uniform = h->ch_uniform = true;
+    h->eps_min = eps;
+    h->mu_min = mu;
+    if (h->dtype == FDTD2D_F32) {
+        h->ce_u = coef_of<float>(eps, h->dt, h->dx);
+        h->ch_u = coef_of<float>(mu, h->dt, h->dx);
+        h->k_mur = mur_of<float>(eps, mu, h->dt, h->dx);
+    } else {
+        h->ce_u = coef_of<double>(eps, h->dt, h->dx);
+        h->ch_u = coef_of<double>(mu, h->dt, h->dx);
+        h->k_mur = mur_of<double>(eps, mu, h->dt, h->dx);
+    }
+    h->have_mat = true;
+    return 0;
+}
+
+double fdtd2d_courant(const fdtd2d_t *h)
+{
+    if (!h || !h->have_mat) return -1.0;
+    const double c = 1 / std::sqrt(h->eps_min * h->mu_min);
+    return (c * h->dt) / h->dx;
+}
+
+int fdtd2d_upload(fdtd2d_t *h, const void *Ez, const void *Hx, const void *Hy, int host_dtype)
+{
+    if (!h) return FDTD2D_E_ARG;
+    if (host_dtype != FDTD2D_F32 && host_dtype != FDTD2D_F64)
+        return fail(h, FDTD2D_E_ARG, "bad host_dtype");
+    int rc = use_device(h);
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const int s = h->halo;   // stored row of the first owned row
+    if (Ez && (rc = copy_in(h, h->ez[h->cur], Ez, host_dtype, s, h->nrows, h->cols))) return rc;
+    if (Hx && (rc = copy_in(h, h->hx, Hx, host_dtype, s, h->nrows, h->cols - 1))) return rc;
+    const int hy_rows = std::min(h->row0 + h->nrows, h->rows - 1) - h->row0;
+    if (Hy && (rc = copy_in(h, h->hy, Hy, host_dtype, s, hy_rows, h->cols))) return rc;
+    // owned rows are current; halo rows are not until the next exchange
+    h->ev = h->hv = Range{h->row0, h->row0 + h->nrows};
+    return 0;
+}
+
+int fdtd2d_download(fdtd2d_t *h, void *Ez, void *Hx, void *Hy, int host_dtype)
+{
+    if (!h) return FDTD2D_E_ARG;
+    if (host_dtype != FDTD2D_F32 && host_dtype != FDTD2D_F64)
+        return fail(h, FDTD2D_E_ARG, "bad host_dtype");
+    int rc = use_device(h);
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const int r0 = h->row0, r1 = h->row0 + h->nrows;
+    if ((Ez && (h->ev.lo > r0 || h->ev.hi < r1)) || ((Hx || Hy) && (h->hv.lo > r0 || h->hv.hi < r1)))
+        return fail(h, FDTD2D_E_STATE, "owned rows [%d,%d) are not current (Ez [%d,%d), H [%d,%d))",
+                    r0, r1, h->ev.lo, h->ev.hi, h->hv.lo, h->hv.hi);
+    const int s = h->halo;
+    if (Ez && (rc = copy_out(h, h->ez[h->cur], Ez, host_dtype, s, h->nrows, h->cols))) return rc;
+    if (Hx && (rc = copy_out(h, h->hx, Hx, host_dtype, s, h->nrows, h->cols - 1))) return rc;
+    const int hy_rows = std::min(r1, h->rows - 1) - r0;
+    if (Hy && (rc = copy_out(h, h->hy, Hy, host_dtype, s, hy_rows, h->cols))) return rc;
+    return 0;
+}
+
+int fdtd2d_reset(fdtd2d_t *h)
+{
+    if (!h) return FDTD2D_E_ARG;
+    int rc = use_device(h);
+    if (rc) return rc;
+    return zero_fields(h);
+}
+
+int fdtd2d_update_h(fdtd2d_t *h)
+{
+    int rc = need_ready(h);
+    return rc ? rc : do_update_h(h);
+}
+
+int fdtd2d_update_e(fdtd2d_t *h)
+{
+    int rc = need_ready(h);
+    return rc ? rc : do_update_e(h);
+}
+
+int fdtd2d_add_point(fdtd2d_t *h, int row, int col, double amp)
+{
+    if (!h) return FDTD2D_E_ARG;
+    int rc = use_device(h);
+    return rc ? rc : do_add_point(h, row, col, amp);
+}
+
+int fdtd2d_run(fdtd2d_t *h, int nsteps, int src_row, int src_col, const double *amps)
+{
+    int rc = need_ready(h);
+    if (rc) return rc;
+    if (nsteps < 0) return fail(h, FDTD2D_E_ARG, "nsteps < 0");
+    if (amps && (src_row < 0 || src_row >= h->rows || src_col < 0 || src_col >= h->cols))
+        return fail(h, FDTD2D_E_ARG, "source cell (%d,%d) outside the %dx%d grid", src_row,
+                    src_col, h->rows, h->cols);
+    for (int n = 0; n < nsteps; ++n) {
+        if ((rc = do_update_h(h))) return rc;
+        if ((rc = do_update_e(h))) return rc;
+        if (amps && (rc = do_add_point(h, src_row, src_col, amps[n]))) return rc;
+    }
+    return 0;
+}
+
+double fdtd2d_source_amplitude(int src_kind, double t, double fc)
+{
+    const double pi = 3.141592653589793;
+    if (src_kind == FDTD2D_SRC_RICKER) {
+        const double tau = pi * fc * (t - 1 / fc);
+        return (1 - 2 * (tau * tau)) * std::exp(-(tau * tau));
+    }
+    if (src_kind == FDTD2D_SRC_SINUSOIDAL) {
+        const double d = t - 3000 / fc, w = 2 / fc;
+        const double envelope = 1 - std::exp(-(d * d) / (2 * (w * w)));
+        return envelope * std::sin(2 * pi * fc * t);
+    }
+    return 0.0;
+}
+
+int fdtd2d_run_waveform(fdtd2d_t *h, int nsteps, int src_kind, int src_row, int src_col,
+                        double fc, long long step0)
+{
+    if (!h) return FDTD2D_E_ARG;
+    if (nsteps < 0) return fail(h, FDTD2D_E_ARG, "nsteps < 0");
+    if (src_kind == FDTD2D_SRC_NONE) return fdtd2d_run(h, nsteps, 0, 0, nullptr);
+    if (src_kind != FDTD2D_SRC_RICKER && src_kind != FDTD2D_SRC_SINUSOIDAL)
+        return fail(h, FDTD2D_E_ARG, "unknown source kind %d", src_kind);
+    std::vector<double> amps((size_t)nsteps);
+    for (int n = 0; n < nsteps; ++n)
+        amps[n] = fdtd2d_source_amplitude(src_kind, (double)(step0 + n) * h->dt, fc);
+    return fdtd2d_run(h, nsteps, src_row, src_col, amps.data());
+}
+
+int fdtd2d_sync(fdtd2d_t *h)
+{
+    if (!h) return FDTD2D_E_ARG;
+    int rc = use_device(h);
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+long long fdtd2d_halo_bytes(const fdtd2d_t *h)
+{
+    return h ? 3LL * h->halo * h->cols * (long long)h->esz : FDTD2D_E_ARG;
+}
+
+int fdtd2d_halo_pack(fdtd2d_t *h, int side, void *dev_buf)
+{
+    if (!h || !dev_buf) return FDTD2D_E_ARG;
+    int rc = use_device(h), first = 0;
+    if (rc || (rc = halo_rows(h, side, true, &first))) return rc;
+    const int r0 = h->row0, r1 = h->row0 + h->nrows;
+    if (h->ev.lo > r0 || h->ev.hi < r1 || h->hv.lo > r0 || h->hv.hi < r1)
+        return fail(h, FDTD2D_E_STATE, "owned rows are not current; cannot pack a halo message");
+    if (h->nrows < h->halo) return fail(h, FDTD2D_E_STATE, "slab thinner than its halo");
+    return h->dtype == FDTD2D_F32 ? launch_halo<float, true>(h, first, dev_buf)
+                                  : launch_halo<double, true>(h, first, dev_buf);
+}
+
+int fdtd2d_halo_unpack(fdtd2d_t *h, int side, const void *dev_buf)
+{
+    if (!h || !dev_buf) return FDTD2D_E_ARG;
+    int rc = use_device(h), first = 0;
+    if (rc || (rc = halo_rows(h, side, false, &first))) return rc;
+    rc = h->dtype == FDTD2D_F32 ? launch_halo<float, false>(h, first, (void *)dev_buf)
+                                : launch_halo<double, false>(h, first, (void *)dev_buf);
+    if (rc) return rc;
+    // the rows just written extend the current range, provided the owned rows adjoin it
+    if (side == 0) {
+        if (h->ev.lo <= h->row0) h->ev.lo = first;
+        if (h->hv.lo <= h->row0) h->hv.lo = first;
+    } else {
+        if (h->ev.hi >= h->row0 + h->nrows) h->ev.hi = first + h->halo;
+        if (h->hv.hi >= h->row0 + h->nrows) h->hv.hi = first + h->halo;
+    }
+    return 0;
+}
+
+int fdtd2d_timer_start(fdtd2d_t *h)
+{
+    if (!h) return FDTD2D_E_ARG;
+    int rc = use_device(h);
+    if (rc) return rc;
+    HIPCHK(h, hipEventRecord(h->t0, h->stream));
+    return 0;
+}
+
+int fdtd2d_timer_stop(fdtd2d_t *h, float *ms)
+{
+    if (!h || !ms) return FDTD2D_E_ARG;
+    int rc = use_device(h);
+    if (rc) return rc;
+    HIPCHK(h, hipEventRecord(h->t1, h->stream));
+    HIPCHK(h, hipEventSynchronize(h->t1));
+    HIPCHK(h, hipEventElapsedTime(ms, h->t0, h->t1));
+    return 0;
+}
+
+int fdtd2d_bytes_per_cell_step(const fdtd2d_t *h)
+{
+    if (!h) return FDTD2D_E_ARG;
+    const int words = 6 + (h->ce_uniform ? 0 : 1) + (h->ch_uniform ? 0 : 1);
+    return words * (int)h->esz;
+}
+
+void *fdtd2d_device_ptr(fdtd2d_t *h, int field)
+{
+    if (!h) return nullptr;
+    switch (field) {
+    case FDTD2D_FIELD_EZ: return h->ez[h->cur];
+    case FDTD2D_FIELD_HX: return h->hx;
+    case FDTD2D_FIELD_HY: return h->hy;
+    default: return nullptr;
+    }
+}
+
+}  // extern "C"

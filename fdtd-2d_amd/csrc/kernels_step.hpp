@@ -1,0 +1,243 @@
+// Single half-step kernels for gfx950 (CDNA4): the drop-in path behind
+// fdtd2d_update_h / fdtd2d_update_e / fdtd2d_add_point.
+//
+// Arithmetic follows the reference cell for cell (python-src/main.py:12-76) in the
+// engine's type T, one rounding per operation (the library is built with
+// -ffp-contract=off: NumPy never fuses a*b+c), so results are value-identical to the
+// reference run on arrays of type T.
+//
+// Storage: every field is `rows_stored x pitch` elements, row-major, pitch a multiple
+// of 64 elements; element (i, j) of the global grid lives at (i - row_base)*pitch + j.
+// Hx's missing column C-1 and Hy's missing row R-1 exist as permanent zeros.
+// Each lane moves 16 bytes per access (float4 / double2): a wave covers 1 KiB of a row.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace fdtd {
+
+template <class T> struct alignas(16) Vec {
+    static constexpr int N = 16 / sizeof(T);
+    T v[N];
+};
+
+template <class T>
+__device__ __forceinline__ Vec<T> ldv(const T *p) { return *reinterpret_cast<const Vec<T> *>(p); }
+template <class T>
+__device__ __forceinline__ void stv(T *p, const Vec<T> &x) { *reinterpret_cast<Vec<T> *>(p) = x; }
+
+struct Geom {
+    int R, C;           // global grid
+    int row_base;       // global row of stored row 0
+    long long pitch;    // elements per stored row
+};
+
+__host__ __device__ __forceinline__ size_t at(const Geom &g, int i, int j)
+{
+    return (size_t)(i - g.row_base) * (size_t)g.pitch + (size_t)j;
+}
+
+// ---- H half-step: main.py:66-76 ------------------------------------------------------
+// rows [lo, hi) with hi <= R-1, columns 0..C-2.  Each thread owns V columns and marches
+// RPT rows down, carrying Ez[i+1] into the next iteration's Ez[i].
+template <class T, bool CH_ARR, int RPT>
+__global__ __launch_bounds__(256) void k_update_h(const T *__restrict__ ez, T *__restrict__ hx,
+                                                  T *__restrict__ hy, const T *__restrict__ ch,
+                                                  T ch_u, Geom g, int lo, int hi)
+{
+    constexpr int V = Vec<T>::N;
+    const int j0 = (blockIdx.x * blockDim.x + threadIdx.x) * V;
+    const int i0 = lo + (blockIdx.y * blockDim.y + threadIdx.y) * RPT;
+    if (j0 > g.C - 2 || i0 >= hi) return;
+    Vec<T> e = ldv(ez + at(g, i0, j0));
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        const int i = i0 + r;
+        if (i >= hi) break;
+        const size_t o = at(g, i, j0);
+        const Vec<T> en = ldv(ez + o + g.pitch);
+        const T er = (j0 + V < g.C) ? ez[o + V] : T(0);
+        Vec<T> x = ldv(hx + o), y = ldv(hy + o), c;
+        if (CH_ARR) c = ldv(ch + o);
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            if (j0 + v <= g.C - 2) {
+                const T cc = CH_ARR ? c.v[v] : ch_u;
+                const T right = (v + 1 < V) ? e.v[v + 1] : er;
+                x.v[v] = x.v[v] - cc * (en.v[v] - e.v[v]);
+                y.v[v] = y.v[v] + cc * (right - e.v[v]);
+            }
+        }
+        stv(hx + o, x);
+        stv(hy + o, y);
+        e = en;
+    }
+}
+
+// ---- E half-step, stage A: main.py:18-27 ---------------------------------------------
+// rows [lo, hi); writes EVERY cell of those rows into ez_new: interior cells get the curl
+// update, edge cells (row 0, row R-1, column 0, column C-1, padding) a copy of ez_old.
+template <class T, bool CE_ARR, int RPT>
+__global__ __launch_bounds__(256) void k_update_e(const T *__restrict__ ez_old,
+                                                  T *__restrict__ ez_new,
+                                                  const T *__restrict__ hx,
+                                                  const T *__restrict__ hy,
+                                                  const T *__restrict__ ce, T ce_u, Geom g, int lo,
+                                                  int hi)
+{
+    constexpr int V = Vec<T>::N;
+    const int j0 = (blockIdx.x * blockDim.x + threadIdx.x) * V;
+    const int i0 = lo + (blockIdx.y * blockDim.y + threadIdx.y) * RPT;
+    if (j0 >= g.C || i0 >= hi) return;
+    Vec<T> xu;
+    if (i0 >= 1) {
+        xu = ldv(hx + at(g, i0 - 1, j0));
+    } else {
+#pragma unroll
+        for (int v = 0; v < V; ++v) xu.v[v] = T(0);
+    }
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        const int i = i0 + r;
+        if (i >= hi) break;
+        const size_t o = at(g, i, j0);
+        const Vec<T> x = ldv(hx + o), y = ldv(hy + o), e = ldv(ez_old + o);
+        const T yl = (j0 > 0) ? hy[o - 1] : T(0);
+        Vec<T> c, out;
+        if (CE_ARR) c = ldv(ce + o);
+        const bool row_in = (i >= 1) && (i <= g.R - 2);
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const int j = j0 + v;
+            const T cc = CE_ARR ? c.v[v] : ce_u;
+            const T left = (v > 0) ? y.v[v - 1] : yl;
+            const T upd = e.v[v] + ((y.v[v] - left) - (x.v[v] - xu.v[v])) * cc;
+            out.v[v] = (row_in && j >= 1 && j <= g.C - 2) ? upd : e.v[v];
+        }
+        stv(ez_new + o, out);
+        xu = x;
+    }
+}
+
+// ---- E half-step, stages B, C, D: main.py:29-61 -----------------------------------------
+// Every frame cell is a pure function of P (= ez_old) and the new H fields in a small
+// neighbourhood, written to ez_new; nothing here reads ez_new, so there is no ordering
+// hazard between frame cells and the kernel can follow k_update_e on the same stream.
+template <class T, bool CE_ARR> struct FrameCtx {
+    const T *P, *hx, *hy, *ce;
+    T ce_u, k;
+    Geom g;
+    __device__ __forceinline__ T p(int i, int j) const { return P[at(g, i, j)]; }
+    // stage A value (main.py:27); edge cells are untouched by A
+    __device__ T a(int i, int j) const
+    {
+        const size_t o = at(g, i, j);
+        const T e = P[o];
+        if (i < 1 || i > g.R - 2 || j < 1 || j > g.C - 2) return e;
+        const T cc = CE_ARR ? ce[o] : ce_u;
+        return e + ((hy[o] - hy[o - 1]) - (hx[o] - hx[o - g.pitch])) * cc;
+    }
+    // after the left/right bands (main.py:34-41): rows 1..R-2
+    __device__ T b(int i, int j) const
+    {
+        if (i >= 1 && i <= g.R - 2) {
+            if (j < 5) return p(i, j + 1) + k * (a(i, j + 1) - p(i, j));
+            if (j >= g.C - 5) return p(i, j - 1) + k * (a(i, j - 1) - p(i, j));
+        }
+        return a(i, j);
+    }
+    // after the top/bottom bands (main.py:44-51): columns 1..C-2
+    __device__ T c(int i, int j) const
+    {
+        if (j >= 1 && j <= g.C - 2) {
+            if (i < 5) return p(i + 1, j) + k * (b(i + 1, j) - p(i, j));
+            if (i >= g.R - 5) return p(i - 1, j) + k * (b(i - 1, j) - p(i, j));
+        }
+        return b(i, j);
+    }
+    // after the corner rule (main.py:54-61)
+    __device__ T d(int i, int j) const
+    {
+        const bool top = i < 5, bot = i >= g.R - 5, lef = j < 5, rig = j >= g.C - 5;
+        if (top && lef) return (c(i, j + 1) + c(i + 1, j)) / T(2);
+        if (top && rig) return (c(i, j - 1) + c(i + 1, j)) / T(2);
+        if (bot && lef) return (c(i - 1, j) + c(i, j + 1)) / T(2);
+        if (bot && rig) return (c(i - 1, j) + c(i, j - 1)) / T(2);
+        return c(i, j);
+    }
+};
+
+// Thread map: first n_lr threads cover the left/right bands of rows [lo, hi) (16 slots
+// per row: 5 left, 5 right, 6 idle); then, if has_top / has_bot, 5 x C threads each for
+// the horizontal bands.  Rows inside a horizontal band are covered by that band only.
+template <class T, bool CE_ARR>
+__global__ __launch_bounds__(256) void k_frame_mur(FrameCtx<T, CE_ARR> f, T *__restrict__ ez_new,
+                                                   int lo, int hi, int has_top, int has_bot)
+{
+    const Geom &g = f.g;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int vlo = has_top ? (lo > 5 ? lo : 5) : lo;
+    const int vhi = has_bot ? (hi < g.R - 5 ? hi : g.R - 5) : hi;
+    const long long n_lr = (vhi > vlo) ? (long long)(vhi - vlo) * 16 : 0;
+    int i, j;
+    if (t < n_lr) {
+        i = vlo + (int)(t >> 4);
+        const int s = (int)(t & 15);
+        if (s < 5) j = s;
+        else if (s < 10) j = g.C - 10 + s;
+        else return;
+        if (i < 1 || i > g.R - 2) return;   // bands B only touch rows 1..R-2
+    } else {
+        long long u = t - n_lr;
+        const long long band = 5LL * g.C;
+        if (has_top && u < band) {
+            i = (int)(u / g.C);
+            j = (int)(u % g.C);
+        } else {
+            if (has_top) u -= band;
+            if (!has_bot || u >= band) return;
+            i = g.R - 5 + (int)(u / g.C);
+            j = (int)(u % g.C);
+        }
+    }
+    ez_new[at(g, i, j)] = f.d(i, j);
+}
+
+// ---- point source: fdtd.py:34 ---------------------------------------------------------------
+template <class T> __global__ void k_add_point(T *ez, size_t off, double amp)
+{
+    ez[off] = (T)((double)ez[off] + amp);
+}
+
+// ---- coefficient arrays: x -> dt/(x*dx) in T (main.py:27,70,74) ------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void k_coef(T *__restrict__ a, size_t n, T dt, T dx)
+{
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; t < n; t += stride) {
+        const T x = a[t];
+        a[t] = (x != T(0)) ? dt / (x * dx) : T(0);   // padding (0) stays 0
+    }
+}
+
+// ---- halo rows <-> contiguous message (3 fields x nrows x C) ---------------------------------
+template <class T, bool PACK>
+__global__ __launch_bounds__(256) void k_halo(T *__restrict__ f0, T *__restrict__ f1,
+                                              T *__restrict__ f2, T *__restrict__ msg, Geom g,
+                                              int row_first, int nrows)
+{
+    const size_t per = (size_t)nrows * g.C;
+    const size_t n = 3 * per;
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; t < n; t += stride) {
+        const int f = (int)(t / per);
+        const size_t r = t % per;
+        const int i = row_first + (int)(r / g.C), j = (int)(r % g.C);
+        T *fld = f == 0 ? f0 : (f == 1 ? f1 : f2);
+        if (PACK) msg[t] = fld[at(g, i, j)];
+        else fld[at(g, i, j)] = msg[t];
+    }
+}
+
+}  // namespace fdtd

@@ -1,0 +1,246 @@
+"""Device-resident FDTD engine: the fast path of the drop-in.
+
+``Engine`` owns one libfdtd2d handle (one GPU, whole grid or one row slab) and keeps
+Ez/Hx/Hy in HBM across steps; host arrays only cross at upload/download.  It is a
+thin object wrapper over the C ABI -- all arithmetic is in the HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+
+_DT = {np.dtype(np.float32): _abi.F32, np.dtype(np.float64): _abi.F64}
+_BOUNDARY = {"none": _abi.BOUNDARY_NONE, "mur": _abi.BOUNDARY_MUR5, "mur5": _abi.BOUNDARY_MUR5,
+             "pml": _abi.BOUNDARY_PML}
+
+
+def _code(dtype) -> int:
+    try:
+        return _DT[np.dtype(dtype)]
+    except KeyError:
+        raise TypeError(f"unsupported dtype {dtype}; use float32 or float64") from None
+
+
+def _host(a, name):
+    """Borrow a host array: C-contiguous float32/float64, no copy when already so."""
+    a = np.asarray(a)
+    if a.dtype not in _DT:
+        a = a.astype(np.float64)
+    if not a.flags.c_contiguous:
+        a = np.ascontiguousarray(a)
+    return a
+
+
+class Engine:
+    """One grid (or row slab) resident on one MI355X.
+
+    rows, cols : global grid (reference shapes: Ez rows x cols, Hx rows x (cols-1),
+                 Hy (rows-1) x cols, python-src/main.py:79-85)
+    dt, dx     : step sizes (python-src/fdtd.py:16-17)
+    dtype      : arithmetic/storage type on the device, float32 (default) or float64
+    boundary   : "mur" (reference, main.py:29-61) or "none"
+    slab       : None for the whole grid, or (row0, nrows, halo) for a row slab
+    """
+
+    def __init__(self, rows, cols, dt=5e-14, dx=1e-4, dtype=np.float32, boundary="mur",
+                 device=0, slab=None):
+        self._lib = _abi.load()
+        self._h = C.c_void_p()
+        self.rows, self.cols, self.dt, self.dx = int(rows), int(cols), float(dt), float(dx)
+        self.dtype = np.dtype(dtype)
+        self.boundary = boundary
+        code, bcode = _code(dtype), _BOUNDARY[boundary]
+        if slab is None:
+            self.row0, self.nrows, self.halo = 0, self.rows, 0
+            rc = self._lib.fdtd2d_create(C.byref(self._h), self.rows, self.cols, self.dt, self.dx,
+                                         code, bcode, int(device))
+        else:
+            self.row0, self.nrows, self.halo = (int(v) for v in slab)
+            rc = self._lib.fdtd2d_create_slab(C.byref(self._h), self.rows, self.cols, self.row0,
+                                              self.nrows, self.halo, self.dt, self.dx, code, bcode,
+                                              int(device))
+        if rc != 0:
+            msg = self._lib.fdtd2d_last_error(None).decode()
+            self._h = C.c_void_p()
+            raise _abi.Fdtd2dError(rc, msg)
+        self.halo = int(self._lib.fdtd2d_info(self._h, _abi.INFO_HALO))
+
+    # -- lifetime -------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.fdtd2d_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _ck(self, rc):
+        return _abi.check(self._h, rc)
+
+    def info(self, what: int) -> int:
+        return int(self._lib.fdtd2d_info(self._h, what))
+
+    # -- rows this handle stores / owns ------------------------------------------------
+    @property
+    def stored_rows(self):
+        return max(0, self.row0 - self.halo), min(self.rows, self.row0 + self.nrows + self.halo)
+
+    @property
+    def owned_rows(self):
+        return self.row0, self.row0 + self.nrows
+
+    # -- materials ------------------------------------------------------------------
+    def set_materials(self, eps=None, mu=None, *, corner=None, allow_uniform=True):
+        """eps, mu: arrays for the STORED rows (whole grid for a non-slab engine), or
+        scalars, or None for vacuum (material_init(None, ...), main.py:100-106)."""
+        from .api import EPS0, MU0
+        eps = EPS0 if eps is None else eps
+        mu = MU0 if mu is None else mu
+        if np.isscalar(eps) and np.isscalar(mu):
+            self._ck(self._lib.fdtd2d_set_materials_uniform(self._h, float(eps), float(mu)))
+            return self
+        lo, hi = self.stored_rows
+        shape = (hi - lo, self.cols)
+        e = _host(np.broadcast_to(eps, shape) if np.isscalar(eps) else eps, "eps")
+        m = _host(np.broadcast_to(mu, shape) if np.isscalar(mu) else mu, "mu")
+        if e.shape != shape or m.shape != shape:
+            raise ValueError(f"eps/mu must have shape {shape} (stored rows {lo}..{hi}), "
+                             f"got {e.shape} and {m.shape}")
+        if e.dtype != m.dtype:
+            m = m.astype(e.dtype)
+        cptr = None
+        if corner is not None:
+            cptr = (C.c_double * 2)(float(corner[0]), float(corner[1]))
+        self._ck(self._lib.fdtd2d_set_materials(self._h, e.ctypes.data, m.ctypes.data,
+                                                _code(e.dtype), cptr, int(bool(allow_uniform))))
+        return self
+
+    def courant(self) -> float:
+        return float(self._lib.fdtd2d_courant(self._h))
+
+    @property
+    def bytes_per_cell_step(self) -> int:
+        return int(self._lib.fdtd2d_bytes_per_cell_step(self._h))
+
+    # -- field transfer -------------------------------------------------------------
+    def _field_shapes(self):
+        r0, r1 = self.owned_rows
+        return ((self.nrows, self.cols), (self.nrows, self.cols - 1),
+                (min(r1, self.rows - 1) - r0, self.cols))
+
+    def upload(self, Ez=None, Hx=None, Hy=None):
+        """Host -> device for the owned rows (reference shapes, any float dtype)."""
+        arrs, code = [], None
+        for a, shp, nm in zip((Ez, Hx, Hy), self._field_shapes(), ("Ez", "Hx", "Hy")):
+            if a is None:
+                arrs.append(None)
+                continue
+            a = _host(a, nm)
+            if a.shape != shp:
+                raise ValueError(f"{nm} must have shape {shp}, got {a.shape}")
+            if code is None:
+                code = _code(a.dtype)
+            elif _code(a.dtype) != code:
+                a = a.astype(np.float64 if code == _abi.F64 else np.float32)
+            arrs.append(a)
+        if code is None:
+            return self
+        ptr = [None if a is None else a.ctypes.data for a in arrs]
+        self._ck(self._lib.fdtd2d_upload(self._h, ptr[0], ptr[1], ptr[2], code))
+        return self
+
+    def download(self, Ez=None, Hx=None, Hy=None, dtype=None):
+        """Device -> host.  With no arguments returns new arrays (Ez, Hx, Hy) of the
+        engine dtype (or `dtype`); given arrays are filled in place and returned."""
+        shapes = self._field_shapes()
+        given = [Ez, Hx, Hy]
+        if all(a is None for a in given):
+            dt_ = np.dtype(dtype or self.dtype)
+            given = [np.empty(s, dt_) for s in shapes]
+        code = None
+        for a, shp, nm in zip(given, shapes, ("Ez", "Hx", "Hy")):
+            if a is None:
+                continue
+            if not isinstance(a, np.ndarray) or not a.flags.c_contiguous or a.dtype not in _DT:
+                raise TypeError(f"{nm} must be a C-contiguous float32/float64 ndarray")
+            if a.shape != shp:
+                raise ValueError(f"{nm} must have shape {shp}, got {a.shape}")
+            c = _code(a.dtype)
+            if code is not None and c != code:
+                raise TypeError("output arrays must share one dtype")
+            code = c
+        ptr = [None if a is None else a.ctypes.data for a in given]
+        self._ck(self._lib.fdtd2d_download(self._h, ptr[0], ptr[1], ptr[2], code))
+        return tuple(given)
+
+    def reset(self):
+        self._ck(self._lib.fdtd2d_reset(self._h))
+        return self
+
+    # -- hot path -------------------------------------------------------------------
+    def update_h(self):
+        self._ck(self._lib.fdtd2d_update_h(self._h))
+
+    def update_e(self):
+        self._ck(self._lib.fdtd2d_update_e(self._h))
+
+    def add_point(self, row, col, amp):
+        self._ck(self._lib.fdtd2d_add_point(self._h, int(row), int(col), float(amp)))
+
+    def run(self, nsteps, src_row=0, src_col=0, amps=None):
+        """nsteps of H -> E -> source (python-src/fdtd.py:30-34), asynchronous.
+        amps: float64 amplitude per step (None = no source)."""
+        if amps is None:
+            self._ck(self._lib.fdtd2d_run(self._h, int(nsteps), 0, 0, None))
+            return self
+        a = np.ascontiguousarray(amps, dtype=np.float64)
+        if a.shape[0] < nsteps:
+            raise ValueError("amps shorter than nsteps")
+        self._ck(self._lib.fdtd2d_run(self._h, int(nsteps), int(src_row), int(src_col),
+                                      a.ctypes.data_as(C.POINTER(C.c_double))))
+        return self
+
+    def run_waveform(self, nsteps, kind="ricker", src_row=0, src_col=0, fc=30e9, step0=0):
+        k = {"none": _abi.SRC_NONE, "ricker": _abi.SRC_RICKER,
+             "sinusoidal": _abi.SRC_SINUSOIDAL}[kind]
+        self._ck(self._lib.fdtd2d_run_waveform(self._h, int(nsteps), k, int(src_row),
+                                               int(src_col), float(fc), int(step0)))
+        return self
+
+    def sync(self):
+        self._ck(self._lib.fdtd2d_sync(self._h))
+        return self
+
+    # -- halo / stream / timing -----------------------------------------------------------
+    def set_stream(self, hip_stream: int | None):
+        self._ck(self._lib.fdtd2d_set_stream(self._h, hip_stream))
+
+    @property
+    def halo_bytes(self) -> int:
+        return int(self._lib.fdtd2d_halo_bytes(self._h))
+
+    def halo_pack(self, side: int, dev_ptr: int):
+        self._ck(self._lib.fdtd2d_halo_pack(self._h, int(side), dev_ptr))
+
+    def halo_unpack(self, side: int, dev_ptr: int):
+        self._ck(self._lib.fdtd2d_halo_unpack(self._h, int(side), dev_ptr))
+
+    def timer_start(self):
+        self._ck(self._lib.fdtd2d_timer_start(self._h))
+
+    def timer_stop(self) -> float:
+        ms = C.c_float()
+        self._ck(self._lib.fdtd2d_timer_stop(self._h, C.byref(ms)))
+        return float(ms.value)
+
+    @property
+    def step_count(self) -> int:
+        return self.info(_abi.INFO_STEP)

@@ -1,0 +1,197 @@
+/*
+ * fdtd2d.h -- C ABI of libfdtd2d.so, the MI355X (gfx950) engine for the 2D TE-mode
+ * Yee-grid Ez/Hx/Hy leapfrog.
+ *
+ * The reference (skunnavakkam/fdtd-2d) has no FFI for this path: its boundary is
+ * the Python call surface of python-src/main.py as driven by python-src/fdtd.py.
+ * Each entry point below names the reference interface it stands in for; the
+ * ctypes binding a maintainer would add is shown in INTEGRATION.md and lives in
+ * fdtd-2d_amd/_abi.py.
+ *
+ * Conventions
+ *   - plain C types only; no torch/numpy types cross this boundary;
+ *   - return 0 on success, a negative code on failure (FDTD2D_E_*; HIP errors are
+ *     reported as -(1000 + hipError_t)); text via fdtd2d_last_error();
+ *   - host buffers are borrowed for the duration of the call only;
+ *   - the handle owns all device memory; a handle is not thread-safe, distinct
+ *     handles are; no global state except the create-time error string;
+ *   - all launches go to the handle's stream (fdtd2d_set_stream) and are
+ *     asynchronous unless stated; fdtd2d_sync() waits;
+ *   - there is no CPU fallback anywhere: without a usable gfx950 device every
+ *     compute call fails with FDTD2D_E_NODEVICE.
+ *
+ * Index convention = the reference's: first axis row i, second axis column j;
+ * host arrays are row-major: Ez R x C, Hx R x (C-1), Hy (R-1) x C, eps/mu R x C
+ * (python-src/main.py:13-15,79-85).
+ */
+#ifndef FDTD2D_H
+#define FDTD2D_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fdtd2d fdtd2d_t;
+
+/* arithmetic / storage type of the device fields (also used for host buffers) */
+#define FDTD2D_F32 0
+#define FDTD2D_F64 1
+
+/* treatment of the outer 5-cell frame of Ez */
+#define FDTD2D_BOUNDARY_NONE 0 /* frame cells left at their stage-A value (edge cells never change) */
+#define FDTD2D_BOUNDARY_MUR5 1 /* the reference: 5-px first-order Mur + corner rule, main.py:29-61 */
+#define FDTD2D_BOUNDARY_PML  2 /* build-defined absorbing layer for BASELINE config 5 (no reference) */
+
+/* point-source waveforms evaluated by the library (host side, float64) */
+#define FDTD2D_SRC_NONE       0
+#define FDTD2D_SRC_RICKER     1 /* main.py:182-187 */
+#define FDTD2D_SRC_SINUSOIDAL 2 /* main.py:190-195 */
+
+/* field selectors */
+#define FDTD2D_FIELD_EZ 0
+#define FDTD2D_FIELD_HX 1
+#define FDTD2D_FIELD_HY 2
+
+/* error codes */
+#define FDTD2D_E_ARG      (-1)  /* bad argument / unsupported size (grids below 11x11) */
+#define FDTD2D_E_NODEVICE (-2)  /* no gfx950 device / HIP runtime unusable */
+#define FDTD2D_E_NOMEM    (-3)
+#define FDTD2D_E_STATE    (-4)  /* call not valid in the current state (e.g. stale halo) */
+#define FDTD2D_E_COURANT  (-5)  /* Courant number > 1 (fdtd.py:28) */
+/* HIP errors: -(1000 + hipError_t) */
+
+/* info selectors for fdtd2d_info() */
+#define FDTD2D_INFO_ROWS        0
+#define FDTD2D_INFO_COLS        1
+#define FDTD2D_INFO_ROW0        2
+#define FDTD2D_INFO_NROWS       3
+#define FDTD2D_INFO_HALO        4
+#define FDTD2D_INFO_PITCH       5  /* elements per stored row */
+#define FDTD2D_INFO_DTYPE       6
+#define FDTD2D_INFO_BOUNDARY    7
+#define FDTD2D_INFO_DEVICE      8
+#define FDTD2D_INFO_EPS_UNIFORM 9
+#define FDTD2D_INFO_MU_UNIFORM  10
+#define FDTD2D_INFO_E_VALID_LO  11 /* global row range on which Ez is current */
+#define FDTD2D_INFO_E_VALID_HI  12
+#define FDTD2D_INFO_H_VALID_LO  13
+#define FDTD2D_INFO_H_VALID_HI  14
+#define FDTD2D_INFO_STEP        15 /* completed E half-steps since create/upload */
+
+/* ---- lifetime ------------------------------------------------------------------ */
+
+/* Whole-grid engine on one device.  Replaces grid_init (main.py:79-85): fields
+ * start at zero.  rows, cols >= 11 (the staged Mur form). */
+int fdtd2d_create(fdtd2d_t **out, int rows, int cols, double dt, double dx,
+                  int dtype, int boundary, int device);
+
+/* Row-slab engine for the multi-GPU decomposition: owns global rows
+ * [row0, row0+nrows) of a rows x cols grid and keeps `halo` extra rows of every
+ * field on each interior side.  One halo refresh allows up to `halo` full steps. */
+int fdtd2d_create_slab(fdtd2d_t **out, int rows, int cols, int row0, int nrows, int halo,
+                       double dt, double dx, int dtype, int boundary, int device);
+
+void fdtd2d_destroy(fdtd2d_t *h);
+
+/* Message of the last failure on this handle (or of the last failed create when h
+ * is NULL).  Never NULL. */
+const char *fdtd2d_last_error(const fdtd2d_t *h);
+
+long long fdtd2d_info(const fdtd2d_t *h, int what);
+
+/* Use an existing hipStream_t (e.g. torch's current stream) for all launches; NULL
+ * restores the handle's own stream. */
+int fdtd2d_set_stream(fdtd2d_t *h, void *hip_stream);
+
+/* ---- materials ----------------------------------------------------------------- */
+
+/* Replaces material_init (main.py:88-123) as the consumer of eps/mu.  eps and mu
+ * point at the host rows this handle stores, i.e. global rows
+ * [max(0,row0-halo), min(rows,row0+nrows+halo)), row-major with `cols` elements per
+ * row, of type host_dtype.  The library forms ce = dt/(eps*dx) and ch = dt/(mu*dx)
+ * once, in the engine's arithmetic type, exactly as main.py:27,70,74 do per step.
+ * corner = {eps[0,0], mu[0,0]} of the GLOBAL grid (the Mur factor uses only that
+ * cell, main.py:30-31); NULL is allowed when this handle stores global row 0.
+ * allow_uniform != 0 lets the library detect constant arrays and switch to scalar
+ * coefficients (same values, fewer bytes). */
+int fdtd2d_set_materials(fdtd2d_t *h, const void *eps, const void *mu, int host_dtype,
+                         const double *corner, int allow_uniform);
+
+/* material_init(None, ...) path (main.py:103-106) and any other constant medium. */
+int fdtd2d_set_materials_uniform(fdtd2d_t *h, double eps, double mu);
+
+/* Courant number c*dt/dx from the smallest eps and mu given so far (fdtd.py:25-26). */
+double fdtd2d_courant(const fdtd2d_t *h);
+
+/* ---- field transfer ------------------------------------------------------------ */
+
+/* Host -> device for the OWNED rows.  Pointers address the first owned row of each
+ * array in the reference's shapes (Ez: cols per row, Hx: cols-1, Hy: cols; Hy has
+ * no row rows-1).  Any pointer may be NULL (field left as is).  Synchronous. */
+int fdtd2d_upload(fdtd2d_t *h, const void *Ez, const void *Hx, const void *Hy, int host_dtype);
+
+/* Device -> host for the OWNED rows, same layouts.  Synchronous (implies a sync). */
+int fdtd2d_download(fdtd2d_t *h, void *Ez, void *Hx, void *Hy, int host_dtype);
+
+/* Reset fields to zero and the step counter to 0 (grid_init again). */
+int fdtd2d_reset(fdtd2d_t *h);
+
+/* ---- the hot path -------------------------------------------------------------- */
+
+/* update_Hx_Hy(Ez,Hx,Hy,mu,eps,dt,dx), main.py:66-76. */
+int fdtd2d_update_h(fdtd2d_t *h);
+
+/* update_Ez(Ez,Hx,Hy,mu,eps,dt,dx), main.py:12-63 (interior + Mur bands + corners). */
+int fdtd2d_update_e(fdtd2d_t *h);
+
+/* `Ez += source` with one non-zero cell, fdtd.py:34: Ez[row,col] =
+ * round(float64(Ez[row,col]) + amp).  A cell outside this handle's rows is ignored. */
+int fdtd2d_add_point(fdtd2d_t *h, int row, int col, double amp);
+
+/* The loop of fdtd.py:30-34 for nsteps steps: H, E, source.  amps = nsteps float64
+ * amplitudes (host) or NULL for no source.  Asynchronous.  For a slab with
+ * neighbours, nsteps must not exceed the halo validity left. */
+int fdtd2d_run(fdtd2d_t *h, int nsteps, int src_row, int src_col, const double *amps);
+
+/* Same with the waveform evaluated by the library at t = (step0+n)*dt. */
+int fdtd2d_run_waveform(fdtd2d_t *h, int nsteps, int src_kind, int src_row, int src_col,
+                        double fc, long long step0);
+
+/* Waveform scalar (float64), main.py:183-184 / 193-194. */
+double fdtd2d_source_amplitude(int src_kind, double t, double fc);
+
+int fdtd2d_sync(fdtd2d_t *h);
+
+/* ---- row-slab halo exchange (transport is the caller's: RCCL via torch.distributed) -- */
+
+/* Bytes of one halo message: 3 fields x halo rows x cols elements. */
+long long fdtd2d_halo_bytes(const fdtd2d_t *h);
+
+/* Pack the `halo` owned rows nearest to side (0 = top/lower row index, 1 = bottom)
+ * of Ez, Hx, Hy into dev_buf (device memory, fdtd2d_halo_bytes()).  Asynchronous. */
+int fdtd2d_halo_pack(fdtd2d_t *h, int side, void *dev_buf);
+
+/* Unpack a neighbour's message into this handle's halo rows on `side` and mark them
+ * current.  Both sides that have a neighbour must be unpacked to restore validity. */
+int fdtd2d_halo_unpack(fdtd2d_t *h, int side, const void *dev_buf);
+
+/* ---- measurement --------------------------------------------------------------- */
+
+/* HIP events on the handle's stream. stop returns elapsed milliseconds (syncs). */
+int fdtd2d_timer_start(fdtd2d_t *h);
+int fdtd2d_timer_stop(fdtd2d_t *h, float *ms);
+
+/* Algorithmic HBM bytes per cell-step of the current configuration (SURVEY.md
+ * section 8 M2): 24 + 4 per non-uniform coefficient array, times sizeof(T)/4. */
+int fdtd2d_bytes_per_cell_step(const fdtd2d_t *h);
+
+/* Device pointer of a field's storage (row-major, pitch elements per row, first
+ * stored row = global row row0-halo) for zero-copy interop.  NULL on error. */
+void *fdtd2d_device_ptr(fdtd2d_t *h, int field);
+
+const char *fdtd2d_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FDTD2D_H */

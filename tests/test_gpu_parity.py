@@ -1,0 +1,275 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and against
+the golden vectors produced by running the reference.
+
+Bars (stated per test):
+  * device type == array type (float32 vs the reference on float32 arrays; float64 vs the
+    reference default): VALUE-IDENTICAL -- np.array_equal on every field.  The kernels use
+    the reference's per-cell operation order with one rounding per operation
+    (-ffp-contract=off), IEEE division for the coefficients and denormals kept.
+  * float32 device vs the float64 reference: e = max|x - ref| / max|ref| <= 5e-6 at 500
+    steps (config 1), <= 1e-4 up to 2000 steps.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+DT, DX, FC = 5e-14, 1e-4, 30e9
+DTYPES = [("f32", np.float32), ("f64", np.float64)]
+
+
+@pytest.fixture(scope="module")
+def fd():
+    import fdtd2d_amd
+    return fdtd2d_amd
+
+
+@pytest.fixture(scope="module")
+def onp():
+    from oracle import fdtd_numpy
+    return fdtd_numpy
+
+
+@pytest.fixture(scope="module")
+def corc():
+    from oracle import c_oracle
+    return c_oracle
+
+
+def _rel(a, ref):
+    return float(np.abs(a.astype(np.float64) - ref).max() / np.abs(ref).max())
+
+
+def _random_state(rng, r, c, dtype, onp, vary_mu=False):
+    Ez = rng.standard_normal((r, c)).astype(dtype)
+    Hx = (rng.standard_normal((r, c - 1)) * 1e-3).astype(dtype)
+    Hy = (rng.standard_normal((r - 1, c)) * 1e-3).astype(dtype)
+    eps = (onp.EPS0 * rng.uniform(1, 10, (r, c))).astype(dtype)
+    mu = (onp.MU0 * (rng.uniform(1, 3, (r, c)) if vary_mu else np.ones((r, c)))).astype(dtype)
+    return Ez, Hx, Hy, eps, mu
+
+
+# ---- golden vectors from the reference ---------------------------------------------------------
+
+@pytest.mark.parametrize("tag,dtype", DTYPES)
+@pytest.mark.parametrize("name", ["g1_single_48x40", "g6_single_11x11", "g6_single_12x13"])
+def test_dropin_half_steps_match_reference_golden(fd, golden_dir, name, tag, dtype):
+    """update_Hx_Hy / update_Ez drop-ins, in place, value-identical to the reference."""
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    f = lambda k: np.ascontiguousarray(g[k].astype(dtype))
+    Ez, Hx, Hy, eps, mu = f("Ez"), f("Hx"), f("Hy"), f("eps"), f("mu")
+    hx, hy = fd.update_Hx_Hy(Ez, Hx, Hy, mu, eps, DT, DX)
+    assert hx is Hx and hy is Hy
+    assert np.array_equal(Hx, g[f"h_Hx_{tag}"]) and np.array_equal(Hy, g[f"h_Hy_{tag}"])
+    Ez2 = f("Ez")
+    assert fd.update_Ez(Ez2, f("Hx"), f("Hy"), mu, eps, DT, DX) is Ez2
+    assert np.array_equal(Ez2, g[f"e_Ez_{tag}"])
+    fd.update_Ez(Ez, Hx, Hy, mu, eps, DT, DX)
+    assert np.array_equal(Ez, g[f"step_Ez_{tag}"])
+
+
+@pytest.mark.parametrize("tag,dtype", DTYPES)
+@pytest.mark.parametrize("name", ["g2_vacuum_64x64", "g3_disk_64x80", "g4_config1_256x256"])
+def test_time_loop_matches_reference_golden(fd, onp, golden_dir, name, tag, dtype):
+    """Engine.run over the golden loops (Mur band exercised in g2/g3): value-identical at
+    every stored snapshot, fed the reference's own source amplitudes."""
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    r, c = int(g["rows"]), int(g["cols"])
+    sr, sc = (int(v) for v in g["src"])
+    eps = g["eps"].astype(dtype) if "eps" in g.files else np.full((r, c), float(g["eps_uniform"])).astype(dtype)
+    mu = np.full((r, c), onp.MU0).astype(dtype)
+    amps = g["amps"]
+    with fd.Engine(r, c, DT, DX, dtype=dtype) as eng:
+        eng.set_materials(eps, mu)
+        done = 0
+        for s in (int(s) for s in g["snaps"]):
+            eng.run(s - done, sr, sc, amps[done:s])
+            done = s
+            if f"Ez_{tag}_{s}" not in g.files:
+                continue
+            for a, k in zip(eng.download(), ("Ez", "Hx", "Hy")):
+                assert np.array_equal(a, g[f"{k}_{tag}_{s}"]), f"{k} differs at step {s}"
+
+
+def test_config1_fp32_device_vs_fp64_reference(fd, onp, golden_dir):
+    """BASELINE config 1 (256x256 vacuum, 500 steps): fp32 device vs the float64 reference,
+    e <= 5e-6; uniform-material fast path on."""
+    g = np.load(os.path.join(golden_dir, "g4_config1_256x256.npz"))
+    Ez, Hx, Hy = fd.run_fdtd(256, 256, DT, DX, 500, dtype=np.float32)
+    for a, k in ((Ez, "Ez"), (Hx, "Hx"), (Hy, "Hy")):
+        assert _rel(a, g[f"{k}_f64_500"]) <= 5e-6, k
+    # and it is exactly the reference run on float32 arrays
+    assert np.array_equal(Ez, g["Ez_f32_500"])
+
+
+def test_fp32_device_vs_fp64_reference_2000_steps(fd, onp, golden_dir):
+    """64x64 vacuum, 1200 steps with boundary reflections: e <= 1e-4."""
+    g = np.load(os.path.join(golden_dir, "g2_vacuum_64x64.npz"))
+    with fd.Engine(64, 64, DT, DX, dtype=np.float32) as eng:
+        eng.set_materials()
+        eng.run(1200, 32, 32, g["amps"])
+        for a, k in zip(eng.download(), ("Ez", "Hx", "Hy")):
+            assert _rel(a, g[f"{k}_f64_1200"]) <= 1e-4, k
+
+
+# ---- against the oracle on seeded random inputs ------------------------------------------------
+
+SHAPES = [(11, 11), (12, 64), (17, 300), (64, 257), (65, 256), (130, 1030), (300, 19)]
+
+
+@pytest.mark.parametrize("tag,dtype", DTYPES)
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("vary_mu", [False, True])
+def test_random_state_steps_match_oracle(fd, onp, shape, tag, dtype, vary_mu):
+    """Ragged widths (not multiples of the 4-/2-wide vectors or of the 64-element pitch),
+    minimum sizes, array eps and (optionally) array mu; 6 steps; value-identical."""
+    r, c = shape
+    rng = np.random.default_rng(1000 * r + c)
+    Ez, Hx, Hy, eps, mu = _random_state(rng, r, c, dtype, onp, vary_mu)
+    ref = [a.copy() for a in (Ez, Hx, Hy)]
+    amps = rng.standard_normal(6)
+    onp.leapfrog(*ref, eps, mu, DT, DX, 6, r // 3, c // 2, amps=amps)
+    with fd.Engine(r, c, DT, DX, dtype=dtype) as eng:
+        eng.set_materials(eps, mu)
+        assert eng.info(9) == 0 and eng.info(10) == (0 if vary_mu else 1)
+        eng.upload(Ez, Hx, Hy)
+        eng.run(6, r // 3, c // 2, amps)
+        got = eng.download()
+    for a, b, k in zip(got, ref, ("Ez", "Hx", "Hy")):
+        assert np.array_equal(a, b), f"{k} {shape} {tag}"
+
+
+@pytest.mark.parametrize("tag,dtype", DTYPES)
+def test_uniform_fast_path_equals_array_path(fd, onp, tag, dtype):
+    """Scalar-coefficient kernels give the same values as the array kernels."""
+    r, c = 96, 200
+    rng = np.random.default_rng(5)
+    Ez, Hx, Hy, _, _ = _random_state(rng, r, c, dtype, onp)
+    eps = np.full((r, c), 3 * onp.EPS0).astype(dtype)
+    mu = np.full((r, c), onp.MU0).astype(dtype)
+    outs = []
+    for allow in (True, False):
+        with fd.Engine(r, c, DT, DX, dtype=dtype) as eng:
+            eng.set_materials(eps, mu, allow_uniform=allow)
+            assert eng.info(9) == int(allow) and eng.bytes_per_cell_step == (24 if allow else 32) * eng.dtype.itemsize // 4
+            eng.upload(Ez, Hx, Hy)
+            eng.run(10, 40, 100, np.linspace(0, 1, 10))
+            outs.append(eng.download())
+    ref = [a.copy() for a in (Ez, Hx, Hy)]
+    onp.leapfrog(*ref, eps, mu, DT, DX, 10, 40, 100, amps=np.linspace(0, 1, 10))
+    for a, b, c_ in zip(outs[0], outs[1], ref):
+        assert np.array_equal(a, b) and np.array_equal(a, c_)
+
+
+def test_step_wrapper_matches_oracle(fd, onp):
+    """step(E,Hx,Hy,eps,mu,source,t): point spec, dense array and callable sources."""
+    r, c = 40, 48
+    rng = np.random.default_rng(9)
+    Ez, Hx, Hy, eps, mu = _random_state(rng, r, c, np.float64, onp)
+    ref = [a.copy() for a in (Ez, Hx, Hy)]
+    t = 333 * DT
+    onp.leapfrog(*ref, eps, mu, DT, DX, 1, 20, 24, amps=[onp.ricker_amplitude(t, FC)])
+    a = [x.copy() for x in (Ez, Hx, Hy)]
+    out = fd.step(*a, eps, mu, ("ricker", 20, 24, FC), t, dt=DT, dx=DX)
+    assert out[0] is a[0]
+    b = [x.copy() for x in (Ez, Hx, Hy)]
+    fd.step(*b, eps, mu, lambda tt: fd.ricker(r, c, 20, 24, tt, FC), t, dt=DT, dx=DX)
+    for x, y, z in zip(a, b, ref):
+        assert np.array_equal(x, z) and np.array_equal(y, z)
+
+
+def test_denormal_and_signed_zero_inputs(fd, onp):
+    """fp32 denormals appear at the numerical wave front; they must be kept, not flushed."""
+    r, c = 32, 64
+    Ez, Hx, Hy = onp.grid_zeros(r, c, np.float32)
+    Ez[10:20, 10:50] = np.float32(3e-39)           # denormal plateau
+    Ez[5, 5] = np.float32(-0.0)
+    Hx[12, 12] = np.float32(1e-42)
+    eps, mu = onp.vacuum_materials(r, c, np.float32)
+    ref = [a.copy() for a in (Ez, Hx, Hy)]
+    onp.leapfrog(*ref, eps, mu, DT, DX, 4, 16, 32, amps=[0, 1e-40, 0, 0])
+    with fd.Engine(r, c, DT, DX, dtype=np.float32) as eng:
+        eng.set_materials(eps, mu, allow_uniform=False)
+        eng.upload(Ez, Hx, Hy)
+        eng.run(4, 16, 32, [0, 1e-40, 0, 0])
+        got = eng.download()
+    assert np.abs(ref[0]).max() < 1e-37 and np.count_nonzero(ref[0]) > 100
+    for a, b in zip(got, ref):
+        assert np.array_equal(a, b)
+
+
+# ---- larger grids: C oracle, and size-independent properties at full size -----------------------
+
+@pytest.mark.parametrize("tag,dtype", DTYPES)
+def test_1024_ring_resonator_matches_c_oracle(fd, onp, corc, tag, dtype):
+    """1024x1024 with the config-3 ring-resonator eps map, 40 steps, vs the C oracle."""
+    n, steps = 1024, 40
+    eps = onp.ring_resonator_eps(n, n, dtype=dtype)
+    mu = np.full((n, n), onp.MU0).astype(dtype)
+    amps = np.array([onp.ricker_amplitude((600 + i) * DT, FC) for i in range(steps)])
+    sr, sc = int(0.2 * n), int(0.2 * n)
+    ref = onp.grid_zeros(n, n, dtype)
+    corc.run(*ref, eps, mu, DT, DX, steps, sr, sc, amps=amps)
+    with fd.Engine(n, n, DT, DX, dtype=dtype) as eng:
+        eng.set_materials(eps, mu)
+        eng.run(steps, sr, sc, amps)
+        got = eng.download()
+    assert np.abs(ref[0]).max() > 0.1
+    for a, b, k in zip(got, ref, ("Ez", "Hx", "Hy")):
+        assert np.array_equal(a, b), k
+
+
+def test_full_size_config2_properties(fd, onp):
+    """4096x4096 fp32 uniform (BASELINE config 2), 300 steps: (i) linearity -- doubling the
+    source doubles every field exactly (powers of two commute with rounding, absent
+    under/overflow); (ii) four-fold symmetry of a centred source on a square vacuum grid is
+    NOT assumed (the Yee update is not symmetric under i<->j at the boundaries) but the
+    transpose relation Hx(i,j) = -Hy(j,i), Ez(i,j) = Ez(j,i) holds away from the frame;
+    (iii) the 256x256 sub-problem: cells the wave has not reached are exactly zero."""
+    n, steps = 4096, 300
+    amps = np.array([onp.ricker_amplitude(i * DT, FC) for i in range(400, 400 + steps)])
+    outs = []
+    for scale in (1.0, 2.0):
+        with fd.Engine(n, n, DT, DX, dtype=np.float32) as eng:
+            eng.set_materials()
+            eng.run(steps, n // 2, n // 2, amps * scale)
+            outs.append(eng.download())
+    for a, b in zip(*outs):
+        big = np.abs(a) > 1e-30           # away from the denormal range scaling is exact
+        assert np.array_equal(a[big] * np.float32(2), b[big])
+    Ez, Hx, Hy = outs[0]
+    assert np.abs(Ez).max() > 0.05
+    reach = int(steps * 0.15) + 40        # Courant 0.15 cells/step + numerical precursor
+    far = np.ones((n, n), bool)
+    far[n // 2 - reach:n // 2 + reach, n // 2 - reach:n // 2 + reach] = False
+    assert not Ez[far].any()
+    w = slice(n // 2 - 60, n // 2 + 60)
+    assert np.array_equal(Ez[w, w], Ez[w, w].T)
+    assert np.array_equal(Hx[w, w], -Hy[w, w].T)
+    # the same window from a small grid (the boundary is out of reach in both)
+    ref = onp.grid_zeros(256, 256, np.float32)
+    e, m = onp.vacuum_materials(256, 256, np.float32)
+    onp.leapfrog(*ref, e, m, DT, DX, steps, 128, 128, amps=amps)
+    assert np.array_equal(Ez[n // 2 - 100:n // 2 + 100, n // 2 - 100:n // 2 + 100],
+                          ref[0][28:228, 28:228])
+
+
+# ---- error behaviour -----------------------------------------------------------------------------
+
+def test_rejects_bad_arguments(fd):
+    with pytest.raises(fd.Fdtd2dError) as ei:
+        fd.Engine(10, 64)
+    assert ei.value.code == -1 and "11x11" in str(ei.value)
+    with fd.Engine(32, 32) as eng:
+        with pytest.raises(fd.Fdtd2dError) as ei:
+            eng.update_h()                 # materials not set
+        assert ei.value.code == -4
+        eng.set_materials()
+        with pytest.raises(fd.Fdtd2dError):
+            eng.add_point(40, 0, 1.0)
+        with pytest.raises(ValueError):
+            eng.upload(np.zeros((31, 32)))
+    with pytest.raises(AssertionError):    # Courant check of fdtd.py:28
+        fd.run_fdtd(32, 32, dt=5e-12, nsteps=1)

@@ -17,6 +17,8 @@ BOUNDARY_NONE, BOUNDARY_MUR5, BOUNDARY_PML = 0, 1, 2
 SRC_NONE, SRC_RICKER, SRC_SINUSOIDAL = 0, 1, 2
 FIELD_EZ, FIELD_HX, FIELD_HY = 0, 1, 2
 
+OPT_MAX_PASS_STEPS, OPT_BAND_ROWS = 0, 1
+
 E_ARG, E_NODEVICE, E_NOMEM, E_STATE, E_COURANT = -1, -2, -3, -4, -5
 
 (INFO_ROWS, INFO_COLS, INFO_ROW0, INFO_NROWS, INFO_HALO, INFO_PITCH, INFO_DTYPE,
@@ -45,6 +47,7 @@ SIGNATURES = {
     "fdtd2d_run": (_i, [_vp, _i, _i, _i, C.POINTER(_d)]),
     "fdtd2d_run_waveform": (_i, [_vp, _i, _i, _i, _i, _d, _ll]),
     "fdtd2d_source_amplitude": (_d, [_i, _d, _d]),
+    "fdtd2d_set_option": (_i, [_vp, _i, _ll]),
     "fdtd2d_sync": (_i, [_vp]),
     "fdtd2d_halo_bytes": (_ll, [_vp]),
     "fdtd2d_halo_pack": (_i, [_vp, _i, _vp]),

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "kernels_step.hpp"
+#include "kernels_stream.hpp"
 
 using fdtd::Geom;
 
@@ -40,7 +41,8 @@ struct fdtd2d {
 
     void *ez[2] = {nullptr, nullptr};
     int cur = 0;                 // ez[cur] is the current Ez
-    void *hx = nullptr, *hy = nullptr;
+    void *hxb[2] = {nullptr, nullptr}, *hyb[2] = {nullptr, nullptr};
+    int hcur = 0;                // hxb[hcur], hyb[hcur] are the current Hx, Hy
     void *ce = nullptr, *ch = nullptr;    // coefficient arrays (nullptr when uniform)
     bool have_mat = false, ce_uniform = true, ch_uniform = true;
     double ce_u = 0, ch_u = 0;   // uniform coefficients, already rounded to T
@@ -60,6 +62,10 @@ struct fdtd2d {
     int store_lo() const { return std::max(0, row0 - halo); }
     int store_hi() const { return std::min(rows, row0 + nrows + halo); }
     Geom geom() const { return Geom{rows, cols, row_base(), pitch}; }
+    void *hx() const { return hxb[hcur]; }
+    void *hy() const { return hyb[hcur]; }
+    int stream_band_rows = 0;    // 0 = heuristic (FDTD2D_BAND_ROWS overrides)
+    int max_nt = 8;              // FDTD2D_MAX_NT overrides; 0 disables the streaming path
 };
 
 namespace {
@@ -186,9 +192,10 @@ int copy_out(fdtd2d *h, const void *dev, void *host, int host_dtype, int srow, i
 
 int zero_fields(fdtd2d *h)
 {
-    for (void *p : {h->ez[0], h->ez[1], h->hx, h->hy})
+    for (void *p : {h->ez[0], h->ez[1], h->hxb[0], h->hxb[1], h->hyb[0], h->hyb[1]})
         HIPCHK(h, hipMemsetAsync(p, 0, h->field_bytes + 256, h->stream));
     h->cur = 0;
+    h->hcur = 0;
     h->ev = h->hv = Range{h->store_lo(), h->store_hi()};
     h->step = 0;
     return 0;
@@ -207,10 +214,10 @@ template <class T> int launch_h(fdtd2d *h, int lo, int hi)
     const T *ez = (const T *)h->ez[h->cur];
     if (h->ch_uniform)
         hipLaunchKernelGGL((fdtd::k_update_h<T, false, RPT>), grid, block, 0, h->stream, ez,
-                           (T *)h->hx, (T *)h->hy, (const T *)nullptr, (T)h->ch_u, g, lo, hi);
+                           (T *)h->hx(), (T *)h->hy(), (const T *)nullptr, (T)h->ch_u, g, lo, hi);
     else
         hipLaunchKernelGGL((fdtd::k_update_h<T, true, RPT>), grid, block, 0, h->stream, ez,
-                           (T *)h->hx, (T *)h->hy, (const T *)h->ch, (T)0, g, lo, hi);
+                           (T *)h->hx(), (T *)h->hy(), (const T *)h->ch, (T)0, g, lo, hi);
     HIPCHK(h, hipGetLastError());
     return 0;
 }
@@ -227,7 +234,7 @@ template <class T, bool CE_ARR> int launch_e_impl(fdtd2d *h, int lo, int hi)
     dim3 grid((unsigned)((h->cols + 64 * V - 1) / (64 * V)),
               (unsigned)((hi - lo + 4 * RPT - 1) / (4 * RPT)));
     hipLaunchKernelGGL((fdtd::k_update_e<T, CE_ARR, RPT>), grid, block, 0, h->stream, ez_old,
-                       ez_new, (const T *)h->hx, (const T *)h->hy, ce, ce_u, g, lo, hi);
+                       ez_new, (const T *)h->hx(), (const T *)h->hy(), ce, ce_u, g, lo, hi);
     HIPCHK(h, hipGetLastError());
     if (h->boundary == FDTD2D_BOUNDARY_MUR5) {
         const int has_top = lo == 0, has_bot = hi == h->rows;
@@ -236,8 +243,8 @@ template <class T, bool CE_ARR> int launch_e_impl(fdtd2d *h, int lo, int hi)
         long long n = (vhi > vlo ? (long long)(vhi - vlo) * 16 : 0) +
                       (long long)(has_top + has_bot) * 5 * h->cols;
         if (n > 0) {
-            fdtd::FrameCtx<T, CE_ARR> f{ez_old, (const T *)h->hx, (const T *)h->hy, ce, ce_u,
-                                        (T)h->k_mur, g};
+            fdtd::FrameCtx<T, CE_ARR> f{{ez_old, (const T *)h->hx(), (const T *)h->hy(), ce, ce_u, g,
+                                         g.R, g.C}, (T)h->k_mur};
             hipLaunchKernelGGL((fdtd::k_frame_mur<T, CE_ARR>), dim3((unsigned)((n + 255) / 256)),
                                dim3(256), 0, h->stream, f, ez_new, lo, hi, has_top, has_bot);
             HIPCHK(h, hipGetLastError());
@@ -309,6 +316,109 @@ int do_add_point(fdtd2d *h, int row, int col, double amp)
     if (row < h->ev.lo || row >= h->ev.hi) return 0;   // not on this slab's current rows
     return h->dtype == FDTD2D_F32 ? launch_point<float>(h, row, col, amp)
                                   : launch_point<double>(h, row, col, amp);
+}
+
+
+// ---- temporally blocked passes (kernels_stream.hpp) ----------------------------------------
+
+// Can a pass of nt steps run from the current state?  Fills the row range of the bulk.
+bool pass_geometry(const fdtd2d *h, int nt, int *band_lo, int *band_hi)
+{
+    if (h->boundary != FDTD2D_BOUNDARY_MUR5 || nt < 1 || nt > h->max_nt) return false;
+    const int zo = 5 + nt, zr = zo + nt + 1;
+    if (h->rows < 2 * zr || h->cols < 16) return false;   // small grids use the single-step path
+    const int lo = h->top() ? zo : h->row0;
+    const int hi = h->bottom() ? h->rows - zo : h->row0 + h->nrows;
+    if (hi - lo < 1) return false;
+    // level-0 rows the bulk reads, and rows the zones read, must be current in E and H
+    const int need_lo = h->top() ? 0 : lo - nt, need_hi = h->bottom() ? h->rows : hi + nt;
+    if (need_lo < std::max(h->ev.lo, h->hv.lo) || need_hi > std::min(h->ev.hi, h->hv.hi)) return false;
+    if (!h->top() && lo - nt < 5) return false;
+    if (!h->bottom() && hi + nt > h->rows - 5) return false;
+    *band_lo = lo;
+    *band_hi = hi;
+    return true;
+}
+
+template <class T, int NT, bool CE_ARR, bool CH_ARR>
+int launch_pass_impl(fdtd2d *h, const fdtd::PassParams<T> &p)
+{
+    constexpr int V = fdtd::Vec<T>::N;
+    constexpr int OW = 64 * V - 2 * fdtd::STREAM_HC;
+    const int region = p.band_hi - p.band_lo;
+    const int nbands = (region + p.band_rows - 1) / p.band_rows;
+    hipLaunchKernelGGL((fdtd::k_stream<T, NT, CE_ARR, CH_ARR>), dim3((unsigned)(nbands * p.nstrips)),
+                       dim3(64), 0, h->stream, p);
+    HIPCHK(h, hipGetLastError());
+    const int nz = p.zone_top + p.zone_bot;
+    if (nz) {
+        const unsigned tiles = (unsigned)((h->cols + fdtd::ZONE_WZ - 1) / fdtd::ZONE_WZ);
+        hipLaunchKernelGGL((fdtd::k_zone<T, NT, CE_ARR, CH_ARR>), dim3(tiles, (unsigned)nz), dim3(256),
+                           0, h->stream, p);
+        HIPCHK(h, hipGetLastError());
+    }
+    (void)OW;
+    return 0;
+}
+
+template <class T, int NT> int launch_pass_nt(fdtd2d *h, const fdtd::PassParams<T> &p)
+{
+    if (h->ce_uniform && h->ch_uniform) return launch_pass_impl<T, NT, false, false>(h, p);
+    if (!h->ce_uniform && h->ch_uniform) return launch_pass_impl<T, NT, true, false>(h, p);
+    if (h->ce_uniform && !h->ch_uniform) return launch_pass_impl<T, NT, false, true>(h, p);
+    return launch_pass_impl<T, NT, true, true>(h, p);
+}
+
+// One pass of nt in {1,2,4,8} steps; amps = nt amplitudes or nullptr.
+template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, int src_row,
+                                   int src_col, const double *amps)
+{
+    constexpr int V = fdtd::Vec<T>::N;
+    constexpr int OW = 64 * V - 2 * fdtd::STREAM_HC;
+    fdtd::PassParams<T> p;
+    p.ez_in = (const T *)h->ez[h->cur];
+    p.hx_in = (const T *)h->hxb[h->hcur];
+    p.hy_in = (const T *)h->hyb[h->hcur];
+    p.ez_out = (T *)h->ez[h->cur ^ 1];
+    p.hx_out = (T *)h->hxb[h->hcur ^ 1];
+    p.hy_out = (T *)h->hyb[h->hcur ^ 1];
+    p.ce = (const T *)h->ce;
+    p.ch = (const T *)h->ch;
+    p.ce_u = (T)h->ce_u;
+    p.ch_u = (T)h->ch_u;
+    p.k = (T)h->k_mur;
+    p.g = h->geom();
+    p.band_lo = band_lo;
+    p.band_hi = band_hi;
+    p.nstrips = (h->cols + OW - 1) / OW;
+    int br = h->stream_band_rows;
+    if (br <= 0) {
+        // aim at ~8 waves per CU on 256 CUs, but keep bands tall enough that the 2*nt rows of
+        // pipeline fill stay a small fraction of the band
+        const int region = band_hi - band_lo;
+        const int want = std::max(1, 2048 / p.nstrips);
+        br = std::max((region + want - 1) / want, 8 * nt);
+    }
+    p.band_rows = std::max(br, 1);
+    p.zone_top = h->top();
+    p.zone_bot = h->bottom();
+    p.src_row = amps ? src_row : -1;
+    p.src_col = amps ? src_col : -1;
+    for (int s = 0; s < fdtd::STREAM_MAX_NT; ++s) p.amp[s] = (amps && s < nt) ? amps[s] : 0.0;
+    int rc;
+    switch (nt) {
+    case 8: rc = launch_pass_nt<T, 8>(h, p); break;
+    case 4: rc = launch_pass_nt<T, 4>(h, p); break;
+    case 2: rc = launch_pass_nt<T, 2>(h, p); break;
+    case 1: rc = launch_pass_nt<T, 1>(h, p); break;
+    default: return fail(h, FDTD2D_E_ARG, "unsupported pass length %d", nt);
+    }
+    if (rc) return rc;
+    h->cur ^= 1;
+    h->hcur ^= 1;
+    h->ev = h->hv = Range{h->top() ? 0 : h->row0, h->bottom() ? h->rows : h->row0 + h->nrows};
+    h->step += nt;
+    return 0;
 }
 
 template <class T> int make_coef(fdtd2d *h, void *arr)
@@ -407,11 +517,13 @@ int create_impl(fdtd2d_t **out, int rows, int cols, int row0, int nrows, int hal
     h->stream = h->own_stream;
     if (hipEventCreate(&h->t0) != hipSuccess || hipEventCreate(&h->t1) != hipSuccess)
         return bail(fail(h, FDTD2D_E_NODEVICE, "hipEventCreate failed"));
-    for (void **p : {&h->ez[0], &h->ez[1], &h->hx, &h->hy}) {
+    for (void **p : {&h->ez[0], &h->ez[1], &h->hxb[0], &h->hxb[1], &h->hyb[0], &h->hyb[1]}) {
         // +256 B guard: the last lane of a row may look one vector past the row end
         if (hipMalloc(p, h->field_bytes + 256) != hipSuccess)
             return bail(fail(h, FDTD2D_E_NOMEM, "hipMalloc of %zu bytes failed", h->field_bytes));
     }
+    if (const char *e2 = std::getenv("FDTD2D_BAND_ROWS")) h->stream_band_rows = std::atoi(e2);
+    if (const char *e2 = std::getenv("FDTD2D_MAX_NT")) h->max_nt = std::atoi(e2);
     rc = zero_fields(h);
     if (rc) return bail(rc);
     if (hipStreamSynchronize(h->stream) != hipSuccess)
@@ -488,7 +600,7 @@ template <class T, bool PACK> int launch_halo(fdtd2d *h, int first, void *buf)
     const size_t n = (size_t)3 * h->halo * h->cols;
     const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 2048);
     hipLaunchKernelGGL((fdtd::k_halo<T, PACK>), dim3(blocks), dim3(256), 0, h->stream,
-                       (T *)h->ez[h->cur], (T *)h->hx, (T *)h->hy, (T *)buf, h->geom(), first,
+                       (T *)h->ez[h->cur], (T *)h->hx(), (T *)h->hy(), (T *)buf, h->geom(), first,
                        h->halo);
     HIPCHK(h, hipGetLastError());
     return 0;
@@ -519,7 +631,7 @@ void fdtd2d_destroy(fdtd2d_t *h)
     if (!h) return;
     if (hipSetDevice(h->device) == hipSuccess) {
         if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
-        for (void *p : {h->ez[0], h->ez[1], h->hx, h->hy, h->ce, h->ch})
+        for (void *p : {h->ez[0], h->ez[1], h->hxb[0], h->hxb[1], h->hyb[0], h->hyb[1], h->ce, h->ch})
             if (p) (void)hipFree(p);
         if (h->t0) (void)hipEventDestroy(h->t0);
         if (h->t1) (void)hipEventDestroy(h->t1);
@@ -616,9 +728,9 @@ int fdtd2d_upload(fdtd2d_t *h, const void *Ez, const void *Hx, const void *Hy, i
     HIPCHK(h, hipStreamSynchronize(h->stream));
     const int s = h->halo;   // stored row of the first owned row
     if (Ez && (rc = copy_in(h, h->ez[h->cur], Ez, host_dtype, s, h->nrows, h->cols))) return rc;
-    if (Hx && (rc = copy_in(h, h->hx, Hx, host_dtype, s, h->nrows, h->cols - 1))) return rc;
+    if (Hx && (rc = copy_in(h, h->hx(), Hx, host_dtype, s, h->nrows, h->cols - 1))) return rc;
     const int hy_rows = std::min(h->row0 + h->nrows, h->rows - 1) - h->row0;
-    if (Hy && (rc = copy_in(h, h->hy, Hy, host_dtype, s, hy_rows, h->cols))) return rc;
+    if (Hy && (rc = copy_in(h, h->hy(), Hy, host_dtype, s, hy_rows, h->cols))) return rc;
     // owned rows are current; halo rows are not until the next exchange
     h->ev = h->hv = Range{h->row0, h->row0 + h->nrows};
     return 0;
@@ -638,9 +750,9 @@ int fdtd2d_download(fdtd2d_t *h, void *Ez, void *Hx, void *Hy, int host_dtype)
                     r0, r1, h->ev.lo, h->ev.hi, h->hv.lo, h->hv.hi);
     const int s = h->halo;
     if (Ez && (rc = copy_out(h, h->ez[h->cur], Ez, host_dtype, s, h->nrows, h->cols))) return rc;
-    if (Hx && (rc = copy_out(h, h->hx, Hx, host_dtype, s, h->nrows, h->cols - 1))) return rc;
+    if (Hx && (rc = copy_out(h, h->hx(), Hx, host_dtype, s, h->nrows, h->cols - 1))) return rc;
     const int hy_rows = std::min(r1, h->rows - 1) - r0;
-    if (Hy && (rc = copy_out(h, h->hy, Hy, host_dtype, s, hy_rows, h->cols))) return rc;
+    if (Hy && (rc = copy_out(h, h->hy(), Hy, host_dtype, s, hy_rows, h->cols))) return rc;
     return 0;
 }
 
@@ -679,10 +791,24 @@ int fdtd2d_run(fdtd2d_t *h, int nsteps, int src_row, int src_col, const double *
     if (amps && (src_row < 0 || src_row >= h->rows || src_col < 0 || src_col >= h->cols))
         return fail(h, FDTD2D_E_ARG, "source cell (%d,%d) outside the %dx%d grid", src_row,
                     src_col, h->rows, h->cols);
-    for (int n = 0; n < nsteps; ++n) {
+    int n = 0;
+    while (n < nsteps) {
+        // longest temporally blocked pass that fits, else one plain step
+        int nt = 0, lo = 0, hi = 0;
+        for (int c : {8, 4, 2, 1})
+            if (c <= nsteps - n && pass_geometry(h, c, &lo, &hi)) { nt = c; break; }
+        if (nt) {
+            rc = h->dtype == FDTD2D_F32
+                     ? launch_pass<float>(h, nt, lo, hi, src_row, src_col, amps ? amps + n : nullptr)
+                     : launch_pass<double>(h, nt, lo, hi, src_row, src_col, amps ? amps + n : nullptr);
+            if (rc) return rc;
+            n += nt;
+            continue;
+        }
         if ((rc = do_update_h(h))) return rc;
         if ((rc = do_update_e(h))) return rc;
         if (amps && (rc = do_add_point(h, src_row, src_col, amps[n]))) return rc;
+        ++n;
     }
     return 0;
 }
@@ -714,6 +840,22 @@ int fdtd2d_run_waveform(fdtd2d_t *h, int nsteps, int src_kind, int src_row, int 
     for (int n = 0; n < nsteps; ++n)
         amps[n] = fdtd2d_source_amplitude(src_kind, (double)(step0 + n) * h->dt, fc);
     return fdtd2d_run(h, nsteps, src_row, src_col, amps.data());
+}
+
+int fdtd2d_set_option(fdtd2d_t *h, int option, long long value)
+{
+    if (!h) return FDTD2D_E_ARG;
+    switch (option) {
+    case FDTD2D_OPT_MAX_PASS_STEPS:
+        if (value < 0 || value > 8) return fail(h, FDTD2D_E_ARG, "pass length must be 0..8");
+        h->max_nt = (int)value;
+        return 0;
+    case FDTD2D_OPT_BAND_ROWS:
+        if (value < 0) return fail(h, FDTD2D_E_ARG, "band rows must be >= 0");
+        h->stream_band_rows = (int)value;
+        return 0;
+    default: return fail(h, FDTD2D_E_ARG, "unknown option %d", option);
+    }
 }
 
 int fdtd2d_sync(fdtd2d_t *h)
@@ -794,8 +936,8 @@ void *fdtd2d_device_ptr(fdtd2d_t *h, int field)
     if (!h) return nullptr;
     switch (field) {
     case FDTD2D_FIELD_EZ: return h->ez[h->cur];
-    case FDTD2D_FIELD_HX: return h->hx;
-    case FDTD2D_FIELD_HY: return h->hy;
+    case FDTD2D_FIELD_HX: return h->hx();
+    case FDTD2D_FIELD_HY: return h->hy();
     default: return nullptr;
     }
 }

@@ -13,6 +13,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "mur_rules.hpp"
+
 namespace fdtd {
 
 template <class T> struct alignas(16) Vec {
@@ -119,52 +121,20 @@ __global__ __launch_bounds__(256) void k_update_e(const T *__restrict__ ez_old,
 }
 
 // ---- E half-step, stages B, C, D: main.py:29-61 -----------------------------------------
-// Every frame cell is a pure function of P (= ez_old) and the new H fields in a small
-// neighbourhood, written to ez_new; nothing here reads ez_new, so there is no ordering
-// hazard between frame cells and the kernel can follow k_update_e on the same stream.
-template <class T, bool CE_ARR> struct FrameCtx {
-    const T *P, *hx, *hy, *ce;
-    T ce_u, k;
+// Every frame cell is a pure function (mur_rules.hpp) of P (= ez_old) and the new H fields
+// in a small neighbourhood, written to ez_new; nothing here reads ez_new, so there is no
+// ordering hazard between frame cells and the kernel can follow k_update_e on the stream.
+template <class T, bool CE_ARR> struct GlobalAcc {
+    const T *P, *x, *y, *c;
+    T ce_u;
     Geom g;
+    int R, C;
     __device__ __forceinline__ T p(int i, int j) const { return P[at(g, i, j)]; }
-    // stage A value (main.py:27); edge cells are untouched by A
-    __device__ T a(int i, int j) const
-    {
-        const size_t o = at(g, i, j);
-        const T e = P[o];
-        if (i < 1 || i > g.R - 2 || j < 1 || j > g.C - 2) return e;
-        const T cc = CE_ARR ? ce[o] : ce_u;
-        return e + ((hy[o] - hy[o - 1]) - (hx[o] - hx[o - g.pitch])) * cc;
-    }
-    // after the left/right bands (main.py:34-41): rows 1..R-2
-    __device__ T b(int i, int j) const
-    {
-        if (i >= 1 && i <= g.R - 2) {
-            if (j < 5) return p(i, j + 1) + k * (a(i, j + 1) - p(i, j));
-            if (j >= g.C - 5) return p(i, j - 1) + k * (a(i, j - 1) - p(i, j));
-        }
-        return a(i, j);
-    }
-    // after the top/bottom bands (main.py:44-51): columns 1..C-2
-    __device__ T c(int i, int j) const
-    {
-        if (j >= 1 && j <= g.C - 2) {
-            if (i < 5) return p(i + 1, j) + k * (b(i + 1, j) - p(i, j));
-            if (i >= g.R - 5) return p(i - 1, j) + k * (b(i - 1, j) - p(i, j));
-        }
-        return b(i, j);
-    }
-    // after the corner rule (main.py:54-61)
-    __device__ T d(int i, int j) const
-    {
-        const bool top = i < 5, bot = i >= g.R - 5, lef = j < 5, rig = j >= g.C - 5;
-        if (top && lef) return (c(i, j + 1) + c(i + 1, j)) / T(2);
-        if (top && rig) return (c(i, j - 1) + c(i + 1, j)) / T(2);
-        if (bot && lef) return (c(i - 1, j) + c(i, j + 1)) / T(2);
-        if (bot && rig) return (c(i - 1, j) + c(i, j - 1)) / T(2);
-        return c(i, j);
-    }
+    __device__ __forceinline__ T hx(int i, int j) const { return x[at(g, i, j)]; }
+    __device__ __forceinline__ T hy(int i, int j) const { return y[at(g, i, j)]; }
+    __device__ __forceinline__ T ce(int i, int j) const { return CE_ARR ? c[at(g, i, j)] : ce_u; }
 };
+template <class T, bool CE_ARR> using FrameCtx = MurRules<T, GlobalAcc<T, CE_ARR>>;
 
 // Thread map: first n_lr threads cover the left/right bands of rows [lo, hi) (16 slots
 // per row: 5 left, 5 right, 6 idle); then, if has_top / has_bot, 5 x C threads each for
@@ -173,7 +143,7 @@ template <class T, bool CE_ARR>
 __global__ __launch_bounds__(256) void k_frame_mur(FrameCtx<T, CE_ARR> f, T *__restrict__ ez_new,
                                                    int lo, int hi, int has_top, int has_bot)
 {
-    const Geom &g = f.g;
+    const Geom &g = f.m.g;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int vlo = has_top ? (lo > 5 ? lo : 5) : lo;
     const int vhi = has_bot ? (hi < g.R - 5 ? hi : g.R - 5) : hi;

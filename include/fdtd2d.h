@@ -162,6 +162,14 @@ double fdtd2d_source_amplitude(int src_kind, double t, double fc);
 
 int fdtd2d_sync(fdtd2d_t *h);
 
+/* Tuning knobs of fdtd2d_run (results do not depend on them, only speed):
+ *   FDTD2D_OPT_MAX_PASS_STEPS  longest temporally blocked pass, 0..8 (0 = plain single steps
+ *                              with the half-step kernels); default 8
+ *   FDTD2D_OPT_BAND_ROWS       rows per streaming band (0 = heuristic) */
+#define FDTD2D_OPT_MAX_PASS_STEPS 0
+#define FDTD2D_OPT_BAND_ROWS      1
+int fdtd2d_set_option(fdtd2d_t *h, int option, long long value);
+
 /* ---- row-slab halo exchange (transport is the caller's: RCCL via torch.distributed) -- */
 
 /* Bytes of one halo message: 3 fields x halo rows x cols elements. */

@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libfdtd2d.so")
+# FDTD2D_LIB: alternative build of the same library (kernel A/B experiments only)
+LIB_PATH = os.environ.get("FDTD2D_LIB") or os.path.join(HERE, "libfdtd2d.so")
 
 F32, F64 = 0, 1
 BOUNDARY_NONE, BOUNDARY_MUR5, BOUNDARY_PML = 0, 1, 2

@@ -341,27 +341,23 @@ bool pass_geometry(const fdtd2d *h, int nt, int *band_lo, int *band_hi)
 }
 
 template <class T, int NT, bool CE_ARR, bool CH_ARR>
-int launch_pass_impl(fdtd2d *h, const fdtd::PassParams<T> &p)
+int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
 {
-    constexpr int V = fdtd::Vec<T>::N;
-    constexpr int OW = 64 * V - 2 * fdtd::STREAM_HC;
+    using D = fdtd::ZoneDims<NT>;
     const int region = p.band_hi - p.band_lo;
-    const int nbands = (region + p.band_rows - 1) / p.band_rows;
-    hipLaunchKernelGGL((fdtd::k_stream<T, NT, CE_ARR, CH_ARR>), dim3((unsigned)(nbands * p.nstrips)),
-                       dim3(64), 0, h->stream, p);
+    p.nbands = (region + p.band_rows - 1) / p.band_rows;
+    p.zone_tiles = (h->cols + D::WZ - 1) / D::WZ;
+    // with a single strip the "last strip" slot of the launch order stays empty
+    const int strip_slots = p.nstrips == 1 ? 2 : p.nstrips;
+    const long long blocks = (long long)(p.zone_top + p.zone_bot) * p.zone_tiles +
+                             (long long)p.nbands * strip_slots;
+    hipLaunchKernelGGL((fdtd::k_pass<T, NT, CE_ARR, CH_ARR>), dim3((unsigned)blocks), dim3(64), 0,
+                       h->stream, p);
     HIPCHK(h, hipGetLastError());
-    const int nz = p.zone_top + p.zone_bot;
-    if (nz) {
-        const unsigned tiles = (unsigned)((h->cols + fdtd::ZONE_WZ - 1) / fdtd::ZONE_WZ);
-        hipLaunchKernelGGL((fdtd::k_zone<T, NT, CE_ARR, CH_ARR>), dim3(tiles, (unsigned)nz), dim3(256),
-                           0, h->stream, p);
-        HIPCHK(h, hipGetLastError());
-    }
-    (void)OW;
     return 0;
 }
 
-template <class T, int NT> int launch_pass_nt(fdtd2d *h, const fdtd::PassParams<T> &p)
+template <class T, int NT> int launch_pass_nt(fdtd2d *h, fdtd::PassParams<T> &p)
 {
     if (h->ce_uniform && h->ch_uniform) return launch_pass_impl<T, NT, false, false>(h, p);
     if (!h->ce_uniform && h->ch_uniform) return launch_pass_impl<T, NT, true, false>(h, p);
@@ -393,11 +389,13 @@ template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, 
     p.nstrips = (h->cols + OW - 1) / OW;
     int br = h->stream_band_rows;
     if (br <= 0) {
-        // aim at ~8 waves per CU on 256 CUs, but keep bands tall enough that the 2*nt rows of
-        // pipeline fill stay a small fraction of the band
+        // Measured on MI355X (profiles/r01_band_sweep.txt): the pass is fastest with about
+        // 2300 waves in flight (256 CUs x 2 waves x 4 SIMDs, slightly oversubscribed) and
+        // bands of 32..128 rows; shorter bands pay too much pipeline fill, taller ones
+        // leave CUs idle at the tail.
         const int region = band_hi - band_lo;
-        const int want = std::max(1, 2048 / p.nstrips);
-        br = std::max((region + want - 1) / want, 8 * nt);
+        const int want = std::max(1, (2304 + p.nstrips - 1) / p.nstrips);
+        br = std::min(std::max(region / want, 32), 128);
     }
     p.band_rows = std::max(br, 1);
     p.zone_top = h->top();

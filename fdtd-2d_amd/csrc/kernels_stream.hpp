@@ -35,7 +35,6 @@ namespace fdtd {
 
 constexpr int STREAM_HC = 8;        // halo columns per strip side (>= NT, multiple of V)
 constexpr int STREAM_MAX_NT = 8;
-constexpr int ZONE_WZ = 64;         // output columns per zone tile
 
 template <class T> struct PassParams {
     const T *ez_in, *hx_in, *hy_in;
@@ -44,8 +43,10 @@ template <class T> struct PassParams {
     T ce_u, ch_u, k;
     Geom g;
     int band_lo, band_hi;      // rows the streaming kernel produces
-    int band_rows, nstrips;
+    int band_rows, nstrips, nbands;
     int zone_top, zone_bot;    // 1 if this launch owns the grid's top / bottom zone
+    int zone_tiles;            // column tiles per zone; the first (zone_top+zone_bot)*zone_tiles
+                               // workgroups of the launch are zone tiles
     int src_row, src_col;      // -1: no source
     double amp[STREAM_MAX_NT]; // amplitude added after step s = 1..NT of this pass
 };
@@ -70,172 +71,186 @@ __device__ __forceinline__ double from_prev(double x)
     return __builtin_bit_cast(double, (long long)(((unsigned long long)hi << 32) | lo));
 }
 
-template <class T> struct Row3 {
+// One row of the strip on its way through the time levels: the registers of a slot are
+// loaded with level 0 of row r and then updated IN PLACE to level 1, 2, ... NT on the
+// following ticks, so no value is ever copied between registers.
+template <class T, bool CE_ARR, bool CH_ARR> struct Slot {
     Vec<T> e, x, y;
+    Vec<T> ce, ch;   // the row's coefficients ride along (only touched when arrays)
 };
 
+#ifndef STREAM_PF
+#define STREAM_PF 2
+#endif
+
 // ---- the streaming kernel ------------------------------------------------------------------
-template <class T, int NT, bool CE_ARR, bool CH_ARR, bool EDGE>
+// GENERAL = false: every column of the strip is a plain interior column and the point
+// source is outside the wave's dependency cone -- no masks at all.
+// GENERAL = true adds what the reference does at the left/right grid edge and the source:
+//   * cells the reference does not update (Hx, Hy beyond column C-2, Ez in columns 0 and
+//     C-1, padding) keep their value: their coefficient is replaced by 0, and x -/+ 0*d == x
+//     exactly for finite d, so no select is needed;
+//   * the left/right 5-px Mur band of the row (main.py:34-41), under wave-uniform branches
+//     that only the first / last strip takes;
+//   * the point source (fdtd.py:34), under a wave-uniform row test.
+template <class T, int NT, bool CE_ARR, bool CH_ARR, bool GENERAL>
 __device__ __forceinline__ void stream_body(const PassParams<T> &p, const int strip, const int ra,
                                             const int rb)
 {
     constexpr int V = Vec<T>::N;
     constexpr int SW = 64 * V, OW = SW - 2 * STREAM_HC;
-    constexpr int U = 4;   // ticks per unrolled loop body = prefetch distance in rows
+    constexpr int PF = STREAM_PF;          // rows in flight ahead of level 0
+    constexpr int S = NT + PF + 2;         // ring of row slots; the tick loop is unrolled S times
     const Geom g = p.g;
     const int lane = threadIdx.x;
-    const int j0 = strip * OW - STREAM_HC + V * lane;
+    const int x0 = strip * OW - STREAM_HC;
+    const int j0 = x0 + V * lane;
     const bool ld_ok = j0 >= 0 && j0 < g.C;
     const bool st_ok = ld_ok && j0 >= strip * OW && j0 < (strip + 1) * OW;
     const size_t col = (size_t)(ld_ok ? j0 : 0);
-
-    // level state: E[t], HX[t], HY[t] = level t at the row it processed in the previous tick
-    Vec<T> E[NT], HX[NT + 1], HY[NT];
-#pragma unroll
-    for (int t = 0; t <= NT; ++t)
-#pragma unroll
-        for (int v = 0; v < V; ++v) {
-            HX[t].v[v] = T(0);
-            if (t < NT) E[t].v[v] = HY[t].v[v] = T(0);
-        }
-
     const int tau0 = ra - NT, tau1 = rb + NT;   // level-0 rows [tau0, tau1)
 
-    auto load_row = [&](int i) {
-        Row3<T> r;
+    // GENERAL: per-element masks (as 0/1 factors) and band membership, fixed for the strip
+    Vec<T> mh, me;
+    bool in_l[V], in_r[V];
+    const bool has_l = GENERAL && x0 < 5, has_r = GENERAL && x0 + SW > g.C - 5;
+    if (GENERAL) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const int j = j0 + v;
+            mh.v[v] = (j >= 0 && j <= g.C - 2) ? T(1) : T(0);
+            me.v[v] = (j >= 1 && j <= g.C - 2) ? T(1) : T(0);
+            in_l[v] = j >= 0 && j < 5;
+            in_r[v] = j >= g.C - 5 && j < g.C;
+        }
+    }
+
+    Slot<T, CE_ARR, CH_ARR> slot[S];
+#pragma unroll
+    for (int k = 0; k < S; ++k)
+#pragma unroll
+        for (int v = 0; v < V; ++v)
+            slot[k].e.v[v] = slot[k].x.v[v] = slot[k].y.v[v] = slot[k].ce.v[v] = slot[k].ch.v[v] = T(0);
+
+    auto load_row = [&](Slot<T, CE_ARR, CH_ARR> &r, int i) {
         if (ld_ok && i < tau1) {
             const size_t o = at(g, i, 0) + col;
             r.e = ldv(p.ez_in + o);
             r.x = ldv(p.hx_in + o);
             r.y = ldv(p.hy_in + o);
-        } else {
+            if (CE_ARR) r.ce = ldv(p.ce + o);
+            if (CH_ARR) r.ch = ldv(p.ch + o);
+            if (GENERAL) {   // fold the update masks into the row's coefficients once
 #pragma unroll
-            for (int v = 0; v < V; ++v) r.e.v[v] = r.x.v[v] = r.y.v[v] = T(0);
+                for (int v = 0; v < V; ++v) {
+                    if (CE_ARR) r.ce.v[v] = me.v[v] != T(0) ? r.ce.v[v] : T(0);
+                    if (CH_ARR) r.ch.v[v] = mh.v[v] != T(0) ? r.ch.v[v] : T(0);
+                }
+            }
         }
-        return r;
     };
-
-    Row3<T> pre[U];
+    Vec<T> ceu, chu;   // uniform coefficients, masked per element when GENERAL
 #pragma unroll
-    for (int u = 0; u < U; ++u) pre[u] = load_row(tau0 + u);
+    for (int v = 0; v < V; ++v) {
+        ceu.v[v] = GENERAL ? (me.v[v] != T(0) ? p.ce_u : T(0)) : p.ce_u;
+        chu.v[v] = GENERAL ? (mh.v[v] != T(0) ? p.ch_u : T(0)) : p.ch_u;
+    }
 
-    for (int tb = tau0; tb < tau1; tb += U) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int tau = tb + u;
+    for (int k = 0; k < PF; ++k) load_row(slot[k], tau0 + k);
+
+    for (int tb = tau0; tb < tau1; tb += S) {
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+            const int tau = tb + k;        // row tau lives in slot k (tb - tau0 is a multiple of S)
             if (tau >= tau1) break;
-            Vec<T> nE = pre[u].e, nX = pre[u].x, nY = pre[u].y;   // level 0, row tau
-            pre[u] = load_row(tau + U);
+            load_row(slot[(k + PF) % S], tau + PF);
 #pragma unroll
             for (int t = 1; t <= NT; ++t) {
-                const int i = tau - t;    // row this level updates now
-                const Vec<T> &Po = E[t - 1];    // level t-1, row i   (P of this E half-step)
-                Vec<T> cx, cy;
-                if (CH_ARR || CE_ARR) {
-                    const bool ok = ld_ok && i >= tau0;   // rows above tau0 are pipeline fill
-                    const size_t o = ok ? at(g, i, 0) + col : 0;
-                    if (CH_ARR) cx = ldv(p.ch + o);
-                    if (CE_ARR) cy = ldv(p.ce + o);
-                }
+                const int i = tau - t;                                   // row level t updates now
+                // level t is only needed on rows [ra-(NT-t)-1, rb+(NT-t)): skip the rest of the
+                // pipeline fill and drain (wave-uniform)
+                if (i < ra - (NT - t) - 1 || i >= rb + (NT - t)) continue;
+                Slot<T, CE_ARR, CH_ARR> &c = slot[(k - t + 2 * S) % S];      // row i, level t-1 -> t
+                const Slot<T, CE_ARR, CH_ARR> &nx = slot[(k - t + 1 + 2 * S) % S];  // row i+1, level t-1
+                const Slot<T, CE_ARR, CH_ARR> &pv = slot[(k - t - 1 + 2 * S) % S];  // row i-1, level t
                 // H half-step of row i (main.py:66-76)
-                const T e_next_lane = from_next(Po.v[0]);
-                Vec<T> hx, hy, en;
+                const T e_next_lane = from_next(c.e.v[0]);
+                Vec<T> po;      // Ez of row i before this step's E half-step (band rows only)
+                if (GENERAL) po = c.e;
 #pragma unroll
                 for (int v = 0; v < V; ++v) {
-                    const T ch = CH_ARR ? cx.v[v] : p.ch_u;
-                    const T right = (v + 1 < V) ? Po.v[v + 1] : e_next_lane;
-                    hx.v[v] = HX[t - 1].v[v] - ch * (nE.v[v] - Po.v[v]);
-                    hy.v[v] = HY[t - 1].v[v] + ch * (right - Po.v[v]);
-                    if (EDGE) {
-                        const int j = j0 + v;
-                        const bool upd = j >= 0 && j <= g.C - 2;
-                        hx.v[v] = upd ? hx.v[v] : HX[t - 1].v[v];
-                        hy.v[v] = upd ? hy.v[v] : HY[t - 1].v[v];
-                    }
+                    const T ch = CH_ARR ? c.ch.v[v] : (GENERAL ? chu.v[v] : p.ch_u);
+                    const T right = (v + 1 < V) ? c.e.v[v + 1] : e_next_lane;
+                    c.x.v[v] = c.x.v[v] - ch * (nx.e.v[v] - c.e.v[v]);
+                    c.y.v[v] = c.y.v[v] + ch * (right - c.e.v[v]);
                 }
                 // E half-step of row i, stage A (main.py:21-27); rows here are always interior
-                const T hy_prev_lane = from_prev(hy.v[V - 1]);
+                const T hy_prev_lane = from_prev(c.y.v[V - 1]);
 #pragma unroll
                 for (int v = 0; v < V; ++v) {
-                    const T ce = CE_ARR ? cy.v[v] : p.ce_u;
-                    const T left = (v > 0) ? hy.v[v - 1] : hy_prev_lane;
-                    en.v[v] = Po.v[v] + ((hy.v[v] - left) - (hx.v[v] - HX[t].v[v])) * ce;
-                    if (EDGE) {
-                        const int j = j0 + v;
-                        en.v[v] = (j >= 1 && j <= g.C - 2) ? en.v[v] : Po.v[v];
+                    const T ce = CE_ARR ? c.ce.v[v] : (GENERAL ? ceu.v[v] : p.ce_u);
+                    const T left = (v > 0) ? c.y.v[v - 1] : hy_prev_lane;
+                    c.e.v[v] = c.e.v[v] + ((c.y.v[v] - left) - (c.x.v[v] - pv.x.v[v])) * ce;
+                }
+                if (GENERAL) {
+                    // stage B: the 5-px Mur band of this row, B[j] = P[j+-1] + k (A[j+-1] - P[j])
+                    if (has_l) {
+                        const T a_next = from_next(c.e.v[0]);
+                        Vec<T> out;
+#pragma unroll
+                        for (int v = 0; v < V; ++v) {
+                            const T pr = (v + 1 < V) ? po.v[v + 1] : e_next_lane;
+                            const T ar = (v + 1 < V) ? c.e.v[v + 1] : a_next;
+                            const T bl = pr + p.k * (ar - po.v[v]);
+                            out.v[v] = in_l[v] ? bl : c.e.v[v];
+                        }
+                        c.e = out;
+                    }
+                    if (has_r) {
+                        const T a_prev = from_prev(c.e.v[V - 1]), p_prev = from_prev(po.v[V - 1]);
+                        Vec<T> out;
+#pragma unroll
+                        for (int v = 0; v < V; ++v) {
+                            const T pl = (v > 0) ? po.v[v - 1] : p_prev;
+                            const T al = (v > 0) ? c.e.v[v - 1] : a_prev;
+                            const T br = pl + p.k * (al - po.v[v]);
+                            out.v[v] = in_r[v] ? br : c.e.v[v];
+                        }
+                        c.e = out;
+                    }
+                    if (i == p.src_row) {   // point source after step t of this pass (fdtd.py:34)
+#pragma unroll
+                        for (int v = 0; v < V; ++v)
+                            if (j0 + v == p.src_col) c.e.v[v] = (T)((double)c.e.v[v] + p.amp[t - 1]);
                     }
                 }
-                if (EDGE) {
-                    // stage B, left/right 5-px Mur band of this row (main.py:34-41)
-                    const T a_next = from_next(en.v[0]), a_prev = from_prev(en.v[V - 1]);
-                    const T p_prev = from_prev(Po.v[V - 1]);
-                    Vec<T> out;
-#pragma unroll
-                    for (int v = 0; v < V; ++v) {
-                        const int j = j0 + v;
-                        const T pr = (v + 1 < V) ? Po.v[v + 1] : e_next_lane;
-                        const T ar = (v + 1 < V) ? en.v[v + 1] : a_next;
-                        const T pl = (v > 0) ? Po.v[v - 1] : p_prev;
-                        const T al = (v > 0) ? en.v[v - 1] : a_prev;
-                        const T bl = pr + p.k * (ar - Po.v[v]);
-                        const T br = pl + p.k * (al - Po.v[v]);
-                        out.v[v] = (j >= 0 && j < 5) ? bl : ((j >= g.C - 5 && j < g.C) ? br : en.v[v]);
-                    }
-                    en = out;
-                }
-                if (i == p.src_row) {   // point source after step t of this pass (fdtd.py:34)
-#pragma unroll
-                    for (int v = 0; v < V; ++v)
-                        if (j0 + v == p.src_col) en.v[v] = (T)((double)en.v[v] + p.amp[t - 1]);
-                }
-                // level t-1's row i+1 becomes its "previous" row; level t's row i flows on
-                E[t - 1] = nE;
-                HX[t - 1] = nX;
-                HY[t - 1] = nY;
-                nE = en;
-                nX = hx;
-                nY = hy;
             }
-            HX[NT] = nX;
             const int io = tau - NT;
             if (io >= ra && st_ok) {
+                const Slot<T, CE_ARR, CH_ARR> &f = slot[(k - NT + 2 * S) % S];
                 const size_t o = at(g, io, 0) + col;
-                stv(p.ez_out + o, nE);
-                stv(p.hx_out + o, nX);
-                stv(p.hy_out + o, nY);
+                stv(p.ez_out + o, f.e);
+                stv(p.hx_out + o, f.x);
+                stv(p.hy_out + o, f.y);
             }
         }
     }
 }
 
-template <class T, int NT, bool CE_ARR, bool CH_ARR>
-__global__ __launch_bounds__(64) void k_stream(const PassParams<T> p)
-{
-    constexpr int V = Vec<T>::N;
-    constexpr int SW = 64 * V, OW = SW - 2 * STREAM_HC;
-    const int strip = blockIdx.x % p.nstrips, band = blockIdx.x / p.nstrips;
-    const int ra = p.band_lo + band * p.band_rows;
-    const int rb = min(ra + p.band_rows, p.band_hi);
-    if (ra >= rb) return;
-    const int x0 = strip * OW - STREAM_HC;
-    // all SW columns plain interior columns (5 <= j <= C-6)?  wave-uniform
-    if (x0 >= 5 && x0 + SW <= p.g.C - 5)
-        stream_body<T, NT, CE_ARR, CH_ARR, false>(p, strip, ra, rb);
-    else
-        stream_body<T, NT, CE_ARR, CH_ARR, true>(p, strip, ra, rb);
-}
-
-// ---- the top/bottom zone kernel ----------------------------------------------------------------
+// ---- the top/bottom zone tiles ---------------------------------------------------------------
+// One wave per tile: 32 columns x (2 NT + 6) rows of Ez (double-buffered), Hx, Hy in LDS.
 template <int NT> struct ZoneDims {
     static constexpr int ZO = 5 + NT;          // rows written per zone
     static constexpr int ZR = ZO + NT + 1;     // rows held in LDS
     static constexpr int M = NT + 1;           // margin columns per side
-    static constexpr int WL = ZONE_WZ + 2 * M; // columns held in LDS
+    static constexpr int WL = 32;              // columns held in LDS
+    static constexpr int WZ = WL - 2 * M;      // columns written per tile
     static constexpr int WLP = WL + 1;         // padded LDS row
 };
 
 template <class T, bool CE_ARR> struct TileAcc {
-    const T *P, *x, *y;   // LDS tiles, row stride WLP
+    const T *P, *x, *y;   // LDS tiles, row stride wlp
     const T *cearr;
     T ce_u;
     Geom g;
@@ -248,27 +263,27 @@ template <class T, bool CE_ARR> struct TileAcc {
 };
 
 template <class T, int NT, bool CE_ARR, bool CH_ARR>
-__global__ __launch_bounds__(256) void k_zone(const PassParams<T> p)
+__device__ __forceinline__ void zone_body(const PassParams<T> &p, const int tile, const bool bottom)
 {
     using D = ZoneDims<NT>;
+    constexpr int NTH = 64;
     __shared__ T sE[2][D::ZR * D::WLP];
     __shared__ T sX[D::ZR * D::WLP];
     __shared__ T sY[D::ZR * D::WLP];
     const Geom g = p.g;
-    const bool bottom = p.zone_top ? (blockIdx.y == 1) : true;
-    // rows held [z0, z1), rows written [o0, o1)
-    const int z0 = bottom ? g.R - D::ZR : 0, z1 = z0 + D::ZR;
-    const int o0 = bottom ? g.R - D::ZO : 0, o1 = o0 + D::ZO;
-    // columns held [c0, c1), columns written [w0, w1)
-    // the last tile is shifted left to full width (it then recomputes a few columns of its
-    // neighbour, writing identical values) so that the right Mur band never sits next to a
-    // non-physical tile edge
-    const int w0 = min((int)blockIdx.x * ZONE_WZ, max(0, g.C - ZONE_WZ)), w1 = min(w0 + ZONE_WZ, g.C);
-    const int c0 = max(0, w0 - D::M), c1 = min(g.C, w0 + ZONE_WZ + D::M);
+    const int tid = threadIdx.x;
+    // rows held [z0, z0+ZR), rows written [o0, o0+ZO)
+    const int z0 = bottom ? g.R - D::ZR : 0;
+    const int o0 = bottom ? g.R - D::ZO : 0;
+    // columns written [w0, w1), columns held [c0, c1).  The last tile is shifted left to full
+    // width (it recomputes a few columns of its neighbour, writing identical values) so that
+    // the right Mur band never sits next to a non-physical tile edge.
+    const int w0 = min(tile * D::WZ, max(0, g.C - D::WZ)), w1 = min(w0 + D::WZ, g.C);
+    const int c0 = max(0, w0 - D::M), c1 = min(g.C, w0 + D::WZ + D::M);
     const int wl = c1 - c0;
     const int ncell = D::ZR * wl;
 
-    for (int n = threadIdx.x; n < ncell; n += 256) {
+    for (int n = tid; n < ncell; n += NTH) {
         const int li = n / wl, lj = n - li * wl;
         const size_t o = at(g, z0 + li, c0 + lj);
         const int s = li * D::WLP + lj;
@@ -284,7 +299,7 @@ __global__ __launch_bounds__(256) void k_zone(const PassParams<T> p)
         const T *Eo = sE[cur];
         T *En = sE[cur ^ 1];
         // H half-step (main.py:66-76) on every cell whose i+1 / j+1 neighbours are in the tile
-        for (int n = threadIdx.x; n < ncell; n += 256) {
+        for (int n = tid; n < ncell; n += NTH) {
             const int li = n / wl, lj = n - li * wl;
             const int i = z0 + li, j = c0 + lj;
             if (i <= g.R - 2 && j <= g.C - 2 && li + 1 < D::ZR && lj + 1 < wl) {
@@ -298,14 +313,22 @@ __global__ __launch_bounds__(256) void k_zone(const PassParams<T> p)
         __syncthreads();
         // E half-step: stages A-D as one pure function of (Eo, new H) per cell
         MurRules<T, TileAcc<T, CE_ARR>> rules{{Eo, sX, sY, p.ce, p.ce_u, g, g.R, g.C, z0, c0, D::WLP}, p.k};
-        for (int n = threadIdx.x; n < ncell; n += 256) {
+        for (int n = tid; n < ncell; n += NTH) {
             const int li = n / wl, lj = n - li * wl;
             const int i = z0 + li, j = c0 + lj;
             const int s = li * D::WLP + lj;
             // needs the row above and the column to the left inside the tile unless the
             // cell sits on the physical edge (where the rules never look outward)
             const bool ok = (li >= 1 || i == 0) && (lj >= 1 || j == 0);
-            T val = ok ? rules.d(i, j) : Eo[s];
+            T val = Eo[s];
+            if (ok) {
+                if (i >= 5 && i < g.R - 5 && j >= 5 && j < g.C - 5) {   // plain interior cell
+                    const T ce = CE_ARR ? p.ce[at(g, i, j)] : p.ce_u;
+                    val = val + ((sY[s] - sY[s - 1]) - (sX[s] - sX[s - D::WLP])) * ce;
+                } else {
+                    val = rules.d(i, j);
+                }
+            }
             if (i == p.src_row && j == p.src_col) val = (T)((double)val + p.amp[step - 1]);
             En[s] = val;
         }
@@ -315,7 +338,7 @@ __global__ __launch_bounds__(256) void k_zone(const PassParams<T> p)
 
     const T *Ef = sE[cur];
     const int ow = w1 - w0;
-    for (int n = threadIdx.x; n < D::ZO * ow; n += 256) {
+    for (int n = tid; n < D::ZO * ow; n += NTH) {
         const int r = n / ow, q = n - r * ow;
         const int i = o0 + r, j = w0 + q;
         const int s = (i - z0) * D::WLP + (j - c0);
@@ -324,6 +347,44 @@ __global__ __launch_bounds__(256) void k_zone(const PassParams<T> p)
         p.hx_out[o] = sX[s];
         p.hy_out[o] = sY[s];
     }
+}
+
+// ---- one launch per pass -------------------------------------------------------------------------
+// Workgroups (one wave each), in launch order: zone tiles, then the strips that need the
+// GENERAL body (first and last strip: they run longer, so they start first), then the rest.
+#ifndef STREAM_WPE
+#define STREAM_WPE 2   // minimum waves per SIMD the register allocator must leave room for
+#endif
+template <class T, int NT, bool CE_ARR, bool CH_ARR>
+__global__ __launch_bounds__(64, STREAM_WPE) void k_pass(const PassParams<T> p)
+{
+    constexpr int V = Vec<T>::N;
+    constexpr int SW = 64 * V, OW = SW - 2 * STREAM_HC;
+    int b = blockIdx.x;
+    const int nzone = (p.zone_top + p.zone_bot) * p.zone_tiles;
+    if (b < nzone) {
+        const int z = b / p.zone_tiles;
+        zone_body<T, NT, CE_ARR, CH_ARR>(p, b - z * p.zone_tiles, p.zone_top ? z == 1 : true);
+        return;
+    }
+    b -= nzone;
+    // strips in the order 0, last, 1, 2, ...; all bands of one strip are consecutive
+    const int sidx = b / p.nbands, band = b - sidx * p.nbands;
+    const int strip = sidx == 0 ? 0 : (sidx == 1 ? p.nstrips - 1 : sidx - 1);
+    if (sidx == 1 && p.nstrips == 1) return;
+    const int ra = p.band_lo + band * p.band_rows;
+    const int rb = min(ra + p.band_rows, p.band_hi);
+    if (ra >= rb) return;
+    const int x0 = strip * OW - STREAM_HC;
+    // wave-uniform choice: all SW columns plain interior (5 <= j <= C-6) and the source cell
+    // outside the rows/columns this wave ever touches -> mask-free body
+    const bool edge = x0 < 5 || x0 + SW > p.g.C - 5;
+    const bool src = p.src_row >= ra - 2 * NT && p.src_row < rb + NT && p.src_col >= x0 &&
+                     p.src_col < x0 + SW;
+    if (edge || src)
+        stream_body<T, NT, CE_ARR, CH_ARR, true>(p, strip, ra, rb);
+    else
+        stream_body<T, NT, CE_ARR, CH_ARR, false>(p, strip, ra, rb);
 }
 
 }  // namespace fdtd

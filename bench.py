@@ -1,17 +1,32 @@
 #!/usr/bin/env python3
 """Benchmark of the FDTD hot path on MI355X.  Prints ONE JSON line (rank 0).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--grid R] [--materials uniform|array]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--grid R [--cols C]]
+                  [--materials uniform|array|ring] [--no-cpu-baseline]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+      --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one full leapfrog step (H half-step, E half-step with Mur frame, point source)
-over the whole grid.  The N=1 workload is BASELINE.json configs[1]: 4096x4096 fp32 TE-mode,
-uniform eps (synthetic: vacuum, ricker source at the centre).  Fields are zero-initialised
-in HBM before the timed region; only the per-step source amplitude crosses from the host.
+A "step" is one full leapfrog step (H half-step, E half-step with the Mur frame, point
+source) over the whole grid -- fdtd.py:31-34 of the reference.
 
-Reported: metric value = Mcell-steps/s (whole job); roofline = algorithmic bytes per step
-/ average step time measured with HIP events on the engine's stream, against the 8 TB/s
-HBM3E peak; cpu_baseline = the NumPy oracle (a line-for-line structural stand-in for the
-reference's NumPy code) timed on this host on a bounded sample.
+Workloads (all synthetic: zero fields, ricker source at the grid centre, fp32):
+  N = 1  BASELINE.json configs[1]: 4096 x 4096, uniform eps (vacuum), Mur-5 boundary.
+  N > 1  row slabs of 4096 rows per GPU, columns 4096*N, i.e. the grids of BASELINE
+         configs[3] (16384^2 on 4) and configs[4] (32768^2 on 8; Mur-5 frame); one process
+         per GPU, halo exchange over torch.distributed (RCCL).  The same slab shape is also
+         timed on one GPU alone ("single_gpu_same_slab") so that weak-scaling efficiency can
+         be read from one line.
+
+Timing: inputs resident in HBM; W untimed warm-up steps; barrier + device sync; K steps;
+device sync + barrier; max over ranks.  value = cells * K / time.
+
+roofline: the dominant kernel is k_pass (one launch = 8 time steps over the whole slab).
+achieved = algorithmic bytes per launch / average launch duration, where algorithmic bytes
+= cells * steps-per-launch * (24 B + 4 B per non-uniform coefficient array) (SURVEY.md
+section 8 M2) and the duration comes from HIP events recorded on the engine's stream around
+the timed region, divided by the number of launches.  Because a pass keeps 8 time levels in
+registers, the algorithmic rate may exceed the HBM peak: frac > 1 means the kernel moves
+fewer bytes than a one-step-per-pass scheme has to ("traffic" holds the measured bytes).
 """
 import argparse
 import json
@@ -25,14 +40,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 DT, DX, FC = 5e-14, 1e-4, 30e9
-HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+SLAB_ROWS = 4096
 
 
 def cpu_baseline(grid: int, budget_s: float = 12.0):
-    """NumPy oracle (single core, like the reference's NumPy loop) on the same workload,
-    bounded to ~budget_s; plus the multi-threaded C oracle for context."""
-    from oracle import fdtd_numpy as onp
+    """The NumPy oracle -- expression for expression the structure of the reference's NumPy
+    code, single core like it -- on the N=1 workload, bounded to ~budget_s; plus the
+    OpenMP C oracle on all host cores for context.  Baseline, not target."""
     from oracle import c_oracle
+    from oracle import fdtd_numpy as onp
     g = min(grid, 4096)
     Ez, Hx, Hy = onp.grid_zeros(g, g, np.float32)
     eps, mu = onp.vacuum_materials(g, g, np.float32)
@@ -44,30 +61,99 @@ def cpu_baseline(grid: int, budget_s: float = 12.0):
         el = time.perf_counter() - t0
         if el > budget_s or n >= 64:
             break
-    val = g * g * n / el / 1e6
-    out = {"value": round(val, 2), "unit": "Mcell-steps/s", "cores": 1, "kind": "port",
-           "sample": f"NumPy oracle, {g}x{g} fp32 vacuum, {n} steps in {el:.1f}s"}
+    out = {"value": round(g * g * n / el / 1e6, 2), "unit": "Mcell-steps/s", "cores": 1,
+           "kind": "port",
+           "sample": f"NumPy oracle (oracle/fdtd_numpy.py), {g}x{g} fp32 vacuum, {n} steps in {el:.1f}s"}
     try:
         Ez, Hx, Hy = onp.grid_zeros(g, g, np.float32)
         c_oracle.run(Ez, Hx, Hy, eps, mu, DT, DX, 1, g // 2, g // 2)
-        t0 = time.perf_counter()
-        k = 8
+        k, t0 = 8, time.perf_counter()
         c_oracle.run(Ez, Hx, Hy, eps, mu, DT, DX, k, g // 2, g // 2)
         el = time.perf_counter() - t0
         out["c_port"] = {"value": round(g * g * k / el / 1e6, 2), "cores": c_oracle.num_threads(),
                          "sample": f"C oracle (OpenMP), {g}x{g} fp32, {k} steps in {el:.2f}s"}
-    except Exception as exc:  # the C oracle is optional context
+    except Exception as exc:  # context only
         out["c_port"] = {"error": str(exc)}
     return out
+
+
+def amplitudes(fd, first, n):
+    return np.array([fd.ricker_amplitude((first + i) * DT, FC) for i in range(n)])
+
+
+def make_materials(fd, kind, rows, cols, r0=0, r1=None):
+    """eps, mu for global rows [r0, r1) -- scalars for the uniform case."""
+    r1 = rows if r1 is None else r1
+    if kind == "uniform":
+        return None, None
+    if kind == "array":            # uniform values handed over as full arrays, detection off
+        return (np.full((r1 - r0, cols), fd.EPS0, np.float32),
+                np.full((r1 - r0, cols), fd.MU0, np.float32))
+    if kind == "ring":             # BASELINE configs[2] geometry (SURVEY.md section 8 M1)
+        i = np.arange(r0, r1, dtype=np.float64)[:, None]
+        j = np.arange(cols, dtype=np.float64)[None, :]
+        core = (i >= np.floor(0.18 * rows)) & (i < np.floor(0.22 * rows))
+        core = core | (np.abs(np.sqrt((i - 0.54 * rows) ** 2 + (j - 0.50 * cols) ** 2) - 0.30 * rows)
+                       <= 0.02 * rows)
+        eps = np.where(core, 10.0 * fd.EPS0, fd.EPS0).astype(np.float32)
+        return eps, np.full((r1 - r0, cols), fd.MU0, np.float32)
+    raise ValueError(kind)
+
+
+def time_single(fd, rows, cols, steps, warmup, materials, device):
+    """One whole-grid engine on one GPU.  Returns dict(wall_s, event_ms, launches, ...)."""
+    import torch
+    eng = fd.Engine(rows, cols, DT, DX, dtype=np.float32, device=device)
+    eps, mu = make_materials(fd, materials, rows, cols)
+    if eps is None:
+        eng.set_materials()
+    else:
+        eng.set_materials(eps, mu, allow_uniform=(materials != "array"))
+    del eps, mu
+    sr, sc = rows // 2, cols // 2
+    eng.run(warmup, sr, sc, amplitudes(fd, 0, warmup)).sync()
+    amps = amplitudes(fd, warmup, steps)
+    l0 = eng.info(16), eng.info(17)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.timer_start()
+    eng.run(steps, sr, sc, amps)
+    ev_ms = eng.timer_stop()
+    eng.sync()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    res = dict(wall_s=wall, event_ms=ev_ms, pass_launches=eng.info(16) - l0[0],
+               step_launches=eng.info(17) - l0[1], bpc=eng.bytes_per_cell_step)
+    Ez, _, _ = eng.download()
+    assert np.isfinite(Ez).all() and np.abs(Ez).max() > 0, "benchmark produced an empty field"
+    eng.close()
+    return res
+
+
+def roofline_block(cells, steps, r):
+    """Per-launch algorithmic rate of the dominant kernel."""
+    if r["pass_launches"]:
+        launches, name = r["pass_launches"], "k_pass (temporally blocked, up to 8 steps per launch)"
+    else:
+        launches, name = max(1, r["step_launches"] // 2), "k_update_h + k_update_e (one step)"
+    ms = r["event_ms"] / launches
+    bytes_per_launch = cells * steps * r["bpc"] / launches
+    ach = bytes_per_launch / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "kernel": name,
+            "bytes_per_cell_step": r["bpc"], "launches": launches,
+            "avg_launch_ms": round(ms, 5),
+            "algorithmic_bytes_per_launch": int(bytes_per_launch)}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--grid", type=int, default=4096)
-    ap.add_argument("--materials", choices=["uniform", "array"], default="uniform")
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--grid", type=int, default=0, help="rows (default 4096 per GPU)")
+    ap.add_argument("--cols", type=int, default=0, help="columns (default 4096*gpus)")
+    ap.add_argument("--materials", choices=["uniform", "array", "ring"], default="uniform")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -77,54 +163,85 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        sys.exit("multi-GPU bench not wired yet in this revision")
+    if world != args.gpus:
+        sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
+                 f"--nproc-per-node {args.gpus}")
     torch.cuda.set_device(local)
+    rows = args.grid or SLAB_ROWS * world
+    cols = args.cols or (args.grid if args.grid else SLAB_ROWS * world)
+    cells = rows * cols
 
-    n = args.grid
-    amps_w = np.array([fd.ricker_amplitude(i * DT, FC) for i in range(args.warmup)])
-    amps = np.array([fd.ricker_amplitude((args.warmup + i) * DT, FC) for i in range(args.steps)])
-    eng = fd.Engine(n, n, DT, DX, dtype=np.float32, device=local)
-    if args.materials == "uniform":
-        eng.set_materials()
-    else:
-        eps, mu = fd.material_init(None, n, n)
-        eng.set_materials(eps.astype(np.float32), mu.astype(np.float32), allow_uniform=False)
-    eng.run(args.warmup, n // 2, n // 2, amps_w).sync()
+    if world == 1:
+        r = time_single(fd, rows, cols, args.steps, args.warmup, args.materials, local)
+        value = cells * args.steps / r["wall_s"] / 1e6
+        res = {
+            "metric": "Mcell-steps/s", "value": round(value, 1), "unit": "Mcell-steps/s",
+            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(r["wall_s"] * 1e3 / args.steps, 5), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{rows}x{cols} fp32 TE-mode, {args.materials} eps/mu, Mur-5 "
+                                   "boundary, ricker point source at the centre"
+                                   + (" (BASELINE configs[1])" if (rows, cols, args.materials) ==
+                                      (4096, 4096, "uniform") else ""),
+                       "grid": [rows, cols], "materials": args.materials},
+            "roofline": roofline_block(cells, args.steps, r),
+        }
+        if not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(rows)
+        print(json.dumps(res))
+        return
 
+    # ---- N > 1: one process per GPU, row slabs, halo exchange over RCCL ---------------------
+    import torch.distributed as dist
+    from fdtd2d_amd.slab import SlabRunner
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    runner = SlabRunner(rows, cols, DT, DX, dtype=np.float32, device=local)
+    lo, hi = runner.engine.stored_rows
+    eps, mu = make_materials(fd, args.materials, rows, cols, lo, hi)
+    runner.set_materials(eps, mu, allow_uniform=(args.materials != "array"))
+    del eps, mu
+    sr, sc = rows // 2, cols // 2
+    runner.run(args.warmup, sr, sc, amplitudes(fd, 0, args.warmup))
+    amps = amplitudes(fd, args.warmup, args.steps)
+    torch.cuda.synchronize()
+    dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    eng.timer_start()
-    eng.run(args.steps, n // 2, n // 2, amps)
-    ev_ms = eng.timer_stop()
-    eng.sync()
+    runner.run(args.steps, sr, sc, amps)
     torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-
-    cells = n * n
-    bpc = eng.bytes_per_cell_step
-    value = cells * args.steps / wall / 1e6
-    step_ms = ev_ms / args.steps
-    achieved = cells * bpc / (step_ms * 1e-3) / 1e9
-    Ez, _, _ = eng.download()
-    assert np.isfinite(Ez).all() and np.abs(Ez).max() > 0
-    res = {
-        "metric": "Mcell-steps/s", "value": round(value, 1), "unit": "Mcell-steps/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(wall * 1e3 / args.steps, 5), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{n}x{n} fp32 TE-mode, {args.materials} eps/mu, Mur-5 boundary, "
-                               "ricker point source at centre (BASELINE configs[1])",
-                   "grid": [n, n], "materials": args.materials, "kernel_path": "two-kernel step"},
-        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                     "bytes_per_cell_step": bpc, "launch": "one leapfrog step (H + E + frame + source kernels)",
-                     "avg_launch_ms": round(step_ms, 5)},
-    }
-    if not args.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline(n)
-    eng.close()
-    print(json.dumps(res))
+    dist.barrier()
+    torch.cuda.synchronize()
+    wall = torch.tensor([time.perf_counter() - t0], device="cuda")
+    dist.all_reduce(wall, op=dist.ReduceOp.MAX)
+    wall = float(wall.item())
+    ok = runner.sanity()
+    slab = runner.engine.nrows
+    runner.close()
+    if rank == 0:
+        single = time_single(fd, slab, cols, min(args.steps, 96), 16, args.materials, local)
+        single_v = slab * cols * min(args.steps, 96) / single["wall_s"] / 1e6
+        value = cells * args.steps / wall / 1e6
+        bpc = single["bpc"]
+        ach = value * 1e6 * bpc / 1e9
+        res = {
+            "metric": "Mcell-steps/s", "value": round(value, 1), "unit": "Mcell-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(wall * 1e3 / args.steps, 5), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{rows}x{cols} fp32 TE-mode, {args.materials} eps/mu, Mur-5 "
+                                   f"boundary, {world} row slabs of {slab} rows, halo 8 rows of "
+                                   "Ez/Hx/Hy every 8 steps over RCCL send/recv",
+                       "grid": [rows, cols], "materials": args.materials,
+                       "per_gpu_slab": [slab, cols], "fields_finite": bool(ok)},
+            "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS * world,
+                         "unit": "GB/s", "frac": round(ach / (HBM_PEAK_GBS * world), 4),
+                         "traffic": None, "kernel": "k_pass, whole job (all ranks)",
+                         "bytes_per_cell_step": bpc},
+            "weak_scaling": {"single_gpu_same_slab": round(single_v, 1),
+                             "efficiency": round(value / (world * single_v), 4)},
+        }
+        print(json.dumps(res))
+    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -51,6 +51,7 @@ struct fdtd2d {
 
     Range ev{0, 0}, hv{0, 0};    // global rows on which Ez / (Hx,Hy) are current
     long long step = 0;
+    long long pass_launches = 0, step_launches = 0;
 
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -219,6 +220,7 @@ template <class T> int launch_h(fdtd2d *h, int lo, int hi)
         hipLaunchKernelGGL((fdtd::k_update_h<T, true, RPT>), grid, block, 0, h->stream, ez,
                            (T *)h->hx(), (T *)h->hy(), (const T *)h->ch, (T)0, g, lo, hi);
     HIPCHK(h, hipGetLastError());
+    h->step_launches++;
     return 0;
 }
 
@@ -251,6 +253,7 @@ template <class T, bool CE_ARR> int launch_e_impl(fdtd2d *h, int lo, int hi)
         }
     }
     h->cur ^= 1;
+    h->step_launches++;
     return 0;
 }
 
@@ -354,6 +357,7 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
     hipLaunchKernelGGL((fdtd::k_pass<T, NT, CE_ARR, CH_ARR>), dim3((unsigned)blocks), dim3(64), 0,
                        h->stream, p);
     HIPCHK(h, hipGetLastError());
+    h->pass_launches++;
     return 0;
 }
 
@@ -660,6 +664,8 @@ long long fdtd2d_info(const fdtd2d_t *h, int what)
     case FDTD2D_INFO_H_VALID_LO: return h->hv.lo;
     case FDTD2D_INFO_H_VALID_HI: return h->hv.hi;
     case FDTD2D_INFO_STEP: return h->step;
+    case FDTD2D_INFO_PASS_LAUNCHES: return h->pass_launches;
+    case FDTD2D_INFO_STEP_LAUNCHES: return h->step_launches;
     default: return FDTD2D_E_ARG;
     }
 }

@@ -1,0 +1,261 @@
+"""Row-slab decomposition over several MI355X: one process per GPU, torch.distributed
+(backend "nccl" = RCCL over xGMI) as the transport.
+
+Rank r owns global rows [r0, r1) of every field and stores `halo` extra rows on each
+interior side.  One exchange sends the `halo` owned rows next to each cut (Ez, Hx, Hy packed
+into ONE message per neighbour by a device kernel) and is good for `halo` full time steps:
+the engine advances its slab by one temporally blocked pass of `halo` steps, recomputing the
+shrinking halo region redundantly, so the ranks talk once per 8 steps instead of twice per
+step, with 8x larger messages -- the shape that suits point-to-point xGMI links.  The
+arithmetic per cell is unchanged, so the N-GPU result is value-identical to the 1-GPU one.
+
+The path has no collective: neighbours only, send/recv.  Boundary handling: the 5-px Mur
+band's left/right part is row-local (every rank); the top/bottom bands and the corners
+live entirely inside the first / last rank (the planner keeps every cut at least 6 + halo
+rows away from the grid's top and bottom).  The Mur factor and the source amplitude are
+host scalars every rank computes identically; the source cell is applied by every rank
+whose stored rows contain it (owned or halo), which is what the redundant halo computation
+needs.
+
+`SlabRunner` only moves bytes and sequences calls; all field arithmetic happens in the
+engine (HIP kernels behind the C ABI).  The engine class is injectable so that the very
+same sequencing code is exercised on CPU by tests (gloo, world_size >= 2) with an
+oracle-backed stand-in that lives under tests/.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+HALO = 8   # rows per exchange = steps per exchange (the longest temporally blocked pass)
+
+
+def plan_slabs(rows: int, world: int, halo: int = HALO):
+    """Contiguous, balanced row ranges [(r0, r1), ...] for `world` ranks.
+
+    Every cut must keep `6 + halo` rows clear of the grid's top and bottom (the horizontal
+    Mur band with its inputs, plus the neighbour's halo) and every slab must be at least
+    `halo` rows tall (it has to fill a neighbour's halo from owned rows)."""
+    if world < 1:
+        raise ValueError("world must be >= 1")
+    if world == 1:
+        return [(0, rows)]
+    need = max(6 + halo, halo)
+    base, rem = divmod(rows, world)
+    if base < need:
+        raise ValueError(f"{rows} rows cannot be cut into {world} slabs with halo {halo}: "
+                         f"each slab needs at least {need} rows")
+    out, r = [], 0
+    for k in range(world):
+        n = base + (1 if k < rem else 0)
+        out.append((r, r + n))
+        r += n
+    return out
+
+
+def _torch_dtype(np_dtype):
+    import torch
+    return {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64}[np.dtype(np_dtype)]
+
+
+class SlabRunner:
+    """Drives one rank's slab: materials, halo exchange, passes, gather.
+
+    Parameters mirror Engine; `group` is a torch.distributed process group (default: the
+    world), `engine_factory(rows, cols, dt, dx, dtype, boundary, device, slab)` builds the
+    per-rank engine (default: the HIP Engine)."""
+
+    def __init__(self, rows, cols, dt=5e-14, dx=1e-4, dtype=np.float32, boundary="mur", device=0,
+                 halo=HALO, group=None, engine_factory=None):
+        import torch
+        import torch.distributed as dist
+        self.dist, self.torch = dist, torch
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.rows, self.cols, self.dt, self.dx = int(rows), int(cols), float(dt), float(dx)
+        self.dtype = np.dtype(dtype)
+        self.halo = int(halo) if self.world > 1 else 0
+        self.plan = plan_slabs(self.rows, self.world, max(self.halo, 1))
+        self.r0, self.r1 = self.plan[self.rank]
+        if engine_factory is None:
+            from .engine import Engine
+            engine_factory = Engine
+        slab = None if self.world == 1 else (self.r0, self.r1 - self.r0, self.halo)
+        self.engine = engine_factory(self.rows, self.cols, self.dt, self.dx, dtype=self.dtype,
+                                     boundary=boundary, device=device, slab=slab)
+        self.up = self.rank - 1 if self.rank > 0 else None          # neighbour above (lower rows)
+        self.down = self.rank + 1 if self.rank < self.world - 1 else None
+        self.backend = dist.get_backend(group)
+        self.buf_device = getattr(self.engine, "buffer_device", None) or f"cuda:{device}"
+        self._bufs = {}
+        # All device work of this rank (engine kernels, pack/unpack, and -- through the
+        # stream-ordering rules of torch.distributed -- the RCCL transfers) is ordered on ONE
+        # side stream, so the host never has to wait for the GPU inside run().
+        self.stream = None
+        if str(self.buf_device).startswith("cuda"):
+            self.stream = torch.cuda.Stream(device=self.buf_device)
+            self.engine.set_stream(self.stream.cuda_stream)
+        if self.world > 1:
+            n = 3 * self.halo * self.cols
+            td = _torch_dtype(self.dtype)
+            for side, nb in ((0, self.up), (1, self.down)):
+                if nb is None:
+                    continue
+                send = torch.empty(n, dtype=td, device=self.buf_device)
+                recv = torch.empty(n, dtype=td, device=self.buf_device)
+                stage = None
+                if self.backend == "gloo" and send.is_cuda:   # gloo moves host memory only
+                    stage = (torch.empty(n, dtype=td).pin_memory(), torch.empty(n, dtype=td).pin_memory())
+                self._bufs[side] = (send, recv, stage)
+            assert self.engine.halo_bytes == n * self.dtype.itemsize
+        self.steps_done = 0
+
+    # -- setup ----------------------------------------------------------------------------
+    def set_materials(self, eps=None, mu=None, allow_uniform=True):
+        """eps, mu: arrays for THIS rank's stored rows (engine.stored_rows), scalars, or None
+        for vacuum.  The [0,0] cell that fixes the Mur factor is broadcast from rank 0."""
+        torch, dist = self.torch, self.dist
+        from .api import EPS0, MU0
+        e_s = EPS0 if eps is None else eps
+        m_s = MU0 if mu is None else mu
+        scalar = np.isscalar(e_s) and np.isscalar(m_s)
+        c = torch.zeros(2, dtype=torch.float64)
+        if self.rank == 0:
+            c[0] = float(e_s if np.isscalar(e_s) else np.asarray(e_s)[0, 0])
+            c[1] = float(m_s if np.isscalar(m_s) else np.asarray(m_s)[0, 0])
+        c = self._host_collective(c, lambda t: dist.broadcast(t, src=self._global(0), group=self.group))
+        lo = torch.tensor([float(np.min(e_s)), float(np.min(m_s))], dtype=torch.float64)
+        lo = self._host_collective(lo, lambda t: dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group))
+        courant = (1 / np.sqrt(float(lo[0]) * float(lo[1])) * self.dt) / self.dx
+        assert courant <= 1.0, f"Courant stability condition not met: {courant} > 1.0"   # fdtd.py:28
+        if scalar:
+            self.engine.set_materials(float(e_s), float(m_s))
+        else:
+            self.engine.set_materials(e_s, m_s, corner=(float(c[0]), float(c[1])),
+                                      allow_uniform=allow_uniform)
+        return self
+
+    def _global(self, group_rank):
+        if self.group is None:
+            return group_rank
+        return self.dist.get_global_rank(self.group, group_rank)
+
+    def _host_collective(self, t, fn):
+        """Tiny setup-time collectives: NCCL needs device tensors, gloo host ones."""
+        if self.backend == "nccl":
+            d = t.to(self.buf_device)
+            fn(d)
+            return d.cpu()
+        fn(t)
+        return t
+
+    def upload(self, Ez=None, Hx=None, Hy=None):
+        """Arrays for the OWNED rows in the reference's shapes."""
+        self.engine.upload(Ez, Hx, Hy)
+        return self
+
+    # -- the loop ---------------------------------------------------------------------------
+    def exchange(self):
+        """Owned edge rows -> neighbours' halos (Ez, Hx, Hy; `halo` rows each way).
+        Call under `self._on_stream()`."""
+        if self.world == 1:
+            return
+        dist, eng = self.dist, self.engine
+        ops, staged = [], []
+        for side, nb in ((0, self.up), (1, self.down)):
+            if nb is None:
+                continue
+            send, recv, stage = self._bufs[side]
+            eng.halo_pack(side, send.data_ptr())
+            if stage is not None:             # gloo with device buffers (tests): via host
+                eng.sync()
+                stage[0].copy_(send)
+                s, r = stage
+                staged.append((recv, r))
+            else:
+                s, r = send, recv
+            peer = self._global(nb)
+            ops.append(dist.P2POp(dist.isend, s, peer, self.group))
+            ops.append(dist.P2POp(dist.irecv, r, peer, self.group))
+        # nccl: the transfers are enqueued behind the pack kernels (current stream) and
+        # wait() makes the current stream wait for them -- no host synchronisation
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        for recv, r in staged:
+            recv.copy_(r)
+        for side, nb in ((0, self.up), (1, self.down)):
+            if nb is not None:
+                eng.halo_unpack(side, self._bufs[side][1].data_ptr())
+
+    def _on_stream(self):
+        import contextlib
+        return self.torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
+
+    def run(self, nsteps, src_row=0, src_col=0, amps=None):
+        """nsteps of H -> E -> source (fdtd.py:30-34) on the whole decomposed grid."""
+        if amps is not None:
+            amps = np.ascontiguousarray(amps, dtype=np.float64)
+            if amps.shape[0] < nsteps:
+                raise ValueError("amps shorter than nsteps")
+        done = 0
+        with self._on_stream():
+            while done < nsteps:
+                n = nsteps - done if self.world == 1 else min(self.halo, nsteps - done)
+                self.exchange()
+                self.engine.run(n, src_row, src_col, None if amps is None else amps[done:done + n])
+                done += n
+        self.steps_done += nsteps
+        return self
+
+    # -- results ----------------------------------------------------------------------------
+    def download(self):
+        """This rank's owned rows (Ez, Hx, Hy) as host arrays."""
+        return self.engine.download()
+
+    def gather(self, dst=0):
+        """Full fields on rank `dst` (None elsewhere).  Test/diagnostic helper."""
+        parts = self.engine.download()
+        if self.world == 1:
+            return parts
+        out = [None] * self.world if self.rank == dst else None
+        self.dist.gather_object(parts, out, dst=self._global(dst), group=self.group)
+        if self.rank != dst:
+            return None
+        return tuple(np.concatenate([p[k] for p in out], axis=0) for k in range(3))
+
+    def sanity(self) -> bool:
+        Ez, Hx, Hy = self.engine.download()
+        return bool(np.isfinite(Ez).all() and np.isfinite(Hx).all() and np.isfinite(Hy).all())
+
+    def close(self):
+        self.engine.close()
+
+
+def run_fdtd_distributed(rows, cols, dt, dx, nsteps, eps, mu, source, boundary, dtype,
+                         on_frame=None, nframes=200, device=None):
+    """run_fdtd() when launched under torch.distributed (one process per GPU).  Every rank
+    calls it with the same arguments (eps/mu: None, scalars or FULL arrays, sliced here);
+    the full (Ez, Hx, Hy) is returned on rank 0, None elsewhere."""
+    import os
+    import torch.distributed as dist
+    from .api import ricker_amplitude, sinusoidal_amplitude
+    if not dist.is_initialized():
+        raise RuntimeError("run_fdtd(devices>1) needs torch.distributed: launch one process per "
+                           "GPU with `python -m torch.distributed.run --nproc-per-node N ...` and "
+                           "call torch.distributed.init_process_group('nccl') first")
+    device = int(os.environ.get("LOCAL_RANK", "0")) if device is None else device
+    runner = SlabRunner(rows, cols, dt, dx, dtype=dtype, boundary=boundary, device=device)
+    lo, hi = runner.engine.stored_rows
+    sl = lambda a: a if (a is None or np.isscalar(a)) else np.ascontiguousarray(np.asarray(a)[lo:hi])
+    runner.set_materials(sl(eps), sl(mu))
+    amps, sr, sc = None, 0, 0
+    if source is not None:
+        kind, sr, sc, fc = source
+        sr = rows // 2 if sr is None else sr
+        sc = cols // 2 if sc is None else sc
+        f = {"ricker": ricker_amplitude, "sinusoidal": sinusoidal_amplitude}[kind]
+        amps = np.array([f(i * dt, fc) for i in range(nsteps)], dtype=np.float64)
+    runner.run(nsteps, sr, sc, amps)
+    out = runner.gather(0)
+    runner.close()
+    return out

@@ -77,6 +77,8 @@ typedef struct fdtd2d fdtd2d_t;
 #define FDTD2D_INFO_H_VALID_LO  13
 #define FDTD2D_INFO_H_VALID_HI  14
 #define FDTD2D_INFO_STEP        15 /* completed E half-steps since create/upload */
+#define FDTD2D_INFO_PASS_LAUNCHES 16 /* temporally blocked pass kernels launched so far */
+#define FDTD2D_INFO_STEP_LAUNCHES 17 /* single half-step kernels launched so far */
 
 /* ---- lifetime ------------------------------------------------------------------ */
 

@@ -1,0 +1,64 @@
+"""Spawns world_size processes that run a SlabRunner job and checks rank 0's gathered result."""
+import os
+import socket
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def worker(rank, world, port, job, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fdtd2d_amd.slab import SlabRunner
+        factory = None
+        if job["engine"] == "fake":
+            from fake_engine import FakeEngine
+            factory = FakeEngine
+        rows, cols = job["shape"]
+        dtype = np.dtype(job["dtype"])
+        runner = SlabRunner(rows, cols, job["dt"], job["dx"], dtype=dtype, device=0,
+                            engine_factory=factory)
+        lo, hi = runner.engine.stored_rows
+        r0, r1 = runner.engine.owned_rows
+        st = np.load(job["state"])
+        if job["materials"] == "uniform":
+            runner.set_materials(float(st["eps"][0, 0]), float(st["mu"][0, 0]))
+        else:
+            runner.set_materials(st["eps"][lo:hi].astype(dtype), st["mu"][lo:hi].astype(dtype))
+        runner.upload(st["Ez"][r0:r1].astype(dtype), st["Hx"][r0:r1].astype(dtype),
+                      st["Hy"][r0:min(r1, rows - 1)].astype(dtype))
+        done = 0
+        for n in job["chunks"]:
+            runner.run(n, job["src"][0], job["src"][1], st["amps"][done:done + n])
+            done += n
+        out = runner.gather(0)
+        if rank == 0:
+            np.savez(os.path.join(outdir, "result.npz"), Ez=out[0], Hx=out[1], Hy=out[2])
+        runner.close()
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_job(world, job, outdir):
+    import torch.multiprocessing as mp
+    port = free_port()
+    mp.spawn(worker, args=(world, port, job, outdir), nprocs=world, join=True)
+    r = np.load(os.path.join(outdir, "result.npz"))
+    return r["Ez"], r["Hx"], r["Hy"]

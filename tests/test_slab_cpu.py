@@ -1,0 +1,72 @@
+"""CPU (gloo, world_size 2 and 3): the row-slab runner -- plan, halo exchange order, source
+handling, chunked runs -- reproduces the single-domain oracle bit for bit.  The per-rank
+engine is the oracle-backed stand-in of tests/fake_engine.py; on the GPU box the same
+harness runs with the real HIP engine (tests/test_gpu_slab.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import fdtd_numpy as onp
+from fdtd2d_amd.slab import plan_slabs
+
+from dist_harness import run_job
+
+DT, DX = 5e-14, 1e-4
+
+
+def test_plan_slabs():
+    assert plan_slabs(100, 1) == [(0, 100)]
+    assert plan_slabs(64, 2) == [(0, 32), (32, 64)]
+    p = plan_slabs(103, 4)
+    assert p[0][0] == 0 and p[-1][1] == 103 and all(a[1] == b[0] for a, b in zip(p, p[1:]))
+    assert max(b - a for a, b in p) - min(b - a for a, b in p) <= 1
+    assert plan_slabs(16384, 4) == [(0, 4096), (4096, 8192), (8192, 12288), (12288, 16384)]
+    with pytest.raises(ValueError):
+        plan_slabs(40, 4)          # 10-row slabs cannot hold the 6+8 row clearance
+
+
+def _state(tmp_path, r, c, seed, nsteps, vary_mu=False):
+    rng = np.random.default_rng(seed)
+    st = dict(Ez=rng.standard_normal((r, c)), Hx=rng.standard_normal((r, c - 1)) * 1e-3,
+              Hy=rng.standard_normal((r - 1, c)) * 1e-3,
+              eps=onp.EPS0 * rng.uniform(1, 10, (r, c)),
+              mu=onp.MU0 * (rng.uniform(1, 3, (r, c)) if vary_mu else np.ones((r, c))),
+              amps=rng.standard_normal(nsteps))
+    path = os.path.join(tmp_path, "state.npz")
+    np.savez(path, **st)
+    return st, path
+
+
+@pytest.mark.parametrize("world,shape,src", [(2, (40, 24), (19, 5)), (2, (41, 30), (20, 29)),
+                                             (3, (66, 20), (22, 3)), (3, (70, 25), (1, 1))])
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_slab_runner_matches_single_domain_oracle(tmp_path, world, shape, src, dtype):
+    """27 steps in chunks (8+8+3, then 8): source on a cut / in a halo / on the frame."""
+    r, c = shape
+    st, path = _state(str(tmp_path), r, c, 11 * r + c, 27, vary_mu=True)
+    job = dict(engine="fake", shape=shape, dtype=dtype, dt=DT, dx=DX, state=path, src=src,
+               chunks=[19, 8], materials="array")
+    got = run_job(world, job, str(tmp_path))
+    dt_ = np.dtype(dtype)
+    ref = [st[k].astype(dt_) for k in ("Ez", "Hx", "Hy")]
+    onp.leapfrog(*ref, st["eps"].astype(dt_), st["mu"].astype(dt_), DT, DX, 27, src[0], src[1],
+                 amps=st["amps"])
+    for a, b, k in zip(got, ref, ("Ez", "Hx", "Hy")):
+        assert a.shape == b.shape and np.array_equal(a, b), k
+
+
+def test_slab_runner_uniform_materials(tmp_path):
+    r, c = 48, 22
+    st, path = _state(str(tmp_path), r, c, 5, 16)
+    st["eps"][:] = 2 * onp.EPS0
+    st["mu"][:] = onp.MU0
+    np.savez(path, **st)
+    job = dict(engine="fake", shape=(r, c), dtype="float32", dt=DT, dx=DX, state=path,
+               src=(24, 11), chunks=[16], materials="uniform")
+    got = run_job(2, job, str(tmp_path))
+    ref = [st[k].astype(np.float32) for k in ("Ez", "Hx", "Hy")]
+    onp.leapfrog(*ref, st["eps"].astype(np.float32), st["mu"].astype(np.float32), DT, DX, 16,
+                 24, 11, amps=st["amps"])
+    for a, b in zip(got, ref):
+        assert np.array_equal(a, b)

@@ -330,14 +330,19 @@ bool pass_geometry(const fdtd2d *h, int nt, int *band_lo, int *band_hi)
     if (h->boundary != FDTD2D_BOUNDARY_MUR5 || nt < 1 || nt > h->max_nt) return false;
     const int zo = 5 + nt, zr = zo + nt + 1;
     if (h->rows < 2 * zr || h->cols < 16) return false;   // small grids use the single-step path
-    const int lo = h->top() ? zo : h->row0;
-    const int hi = h->bottom() ? h->rows - zo : h->row0 + h->nrows;
+    // A pass consumes nt rows of validity on every interior side: from rows [a, b) current
+    // at time n it can produce rows [a+nt, b-nt) at time n+nt (all of them, halo rows
+    // included, so that several passes can follow one halo exchange).
+    const int a = std::max(h->ev.lo, h->hv.lo), b = std::min(h->ev.hi, h->hv.hi);
+    const int lo = h->top() ? zo : a + nt;
+    const int hi = h->bottom() ? h->rows - zo : b - nt;
     if (hi - lo < 1) return false;
-    // level-0 rows the bulk reads, and rows the zones read, must be current in E and H
-    const int need_lo = h->top() ? 0 : lo - nt, need_hi = h->bottom() ? h->rows : hi + nt;
-    if (need_lo < std::max(h->ev.lo, h->hv.lo) || need_hi > std::min(h->ev.hi, h->hv.hi)) return false;
-    if (!h->top() && lo - nt < 5) return false;
-    if (!h->bottom() && hi + nt > h->rows - 5) return false;
+    if (h->top() && a > 0) return false;
+    if (h->bottom() && b < h->rows) return false;
+    if (lo > std::max(h->row0, h->top() ? zo : 0) || hi < std::min(h->row0 + h->nrows, h->bottom() ? h->rows - zo : h->rows))
+        return false;                                  // owned rows would not be covered
+    if (!h->top() && lo - nt < 5) return false;        // bulk rows never touch the top/bottom
+    if (!h->bottom() && hi + nt > h->rows - 5) return false;   // 5-row Mur band at any level
     *band_lo = lo;
     *band_hi = hi;
     return true;
@@ -418,7 +423,7 @@ template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, 
     if (rc) return rc;
     h->cur ^= 1;
     h->hcur ^= 1;
-    h->ev = h->hv = Range{h->top() ? 0 : h->row0, h->bottom() ? h->rows : h->row0 + h->nrows};
+    h->ev = h->hv = Range{h->top() ? 0 : band_lo, h->bottom() ? h->rows : band_hi};
     h->step += nt;
     return 0;
 }

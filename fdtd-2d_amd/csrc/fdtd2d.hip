@@ -66,7 +66,7 @@ struct fdtd2d {
     void *hx() const { return hxb[hcur]; }
     void *hy() const { return hyb[hcur]; }
     int stream_band_rows = 0;    // 0 = heuristic (FDTD2D_BAND_ROWS overrides)
-    int max_nt = 8;              // FDTD2D_MAX_NT overrides; 0 disables the streaming path
+    int max_nt = 8;              // longest pass; FDTD2D_MAX_NT / set_option override (0: step kernels only)
 };
 
 namespace {
@@ -369,9 +369,13 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
 template <class T, int NT> int launch_pass_nt(fdtd2d *h, fdtd::PassParams<T> &p)
 {
     if (h->ce_uniform && h->ch_uniform) return launch_pass_impl<T, NT, false, false>(h, p);
+    if constexpr (NT > 8)   // the coefficient rows do not fit the register budget beyond 8 levels
+        return fail(h, FDTD2D_E_ARG, "passes longer than 8 steps need uniform materials");
+    else {
     if (!h->ce_uniform && h->ch_uniform) return launch_pass_impl<T, NT, true, false>(h, p);
     if (h->ce_uniform && !h->ch_uniform) return launch_pass_impl<T, NT, false, true>(h, p);
     return launch_pass_impl<T, NT, true, true>(h, p);
+    }
 }
 
 // One pass of nt in {1,2,4,8} steps; amps = nt amplitudes or nullptr.
@@ -379,7 +383,7 @@ template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, 
                                    int src_col, const double *amps)
 {
     constexpr int V = fdtd::Vec<T>::N;
-    constexpr int OW = 64 * V - 2 * fdtd::STREAM_HC;
+    const int OW = 64 * V - 2 * fdtd::stream_hc(nt);
     fdtd::PassParams<T> p;
     p.ez_in = (const T *)h->ez[h->cur];
     p.hx_in = (const T *)h->hxb[h->hcur];
@@ -414,6 +418,9 @@ template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, 
     for (int s = 0; s < fdtd::STREAM_MAX_NT; ++s) p.amp[s] = (amps && s < nt) ? amps[s] : 0.0;
     int rc;
     switch (nt) {
+    case 12:
+        if constexpr (sizeof(T) == 4) { rc = launch_pass_nt<T, 12>(h, p); break; }
+        return fail(h, FDTD2D_E_ARG, "12-step passes are built for float32 only");
     case 8: rc = launch_pass_nt<T, 8>(h, p); break;
     case 4: rc = launch_pass_nt<T, 4>(h, p); break;
     case 2: rc = launch_pass_nt<T, 2>(h, p); break;
@@ -804,8 +811,13 @@ int fdtd2d_run(fdtd2d_t *h, int nsteps, int src_row, int src_col, const double *
     while (n < nsteps) {
         // longest temporally blocked pass that fits, else one plain step
         int nt = 0, lo = 0, hi = 0;
-        for (int c : {8, 4, 2, 1})
-            if (c <= nsteps - n && pass_geometry(h, c, &lo, &hi)) { nt = c; break; }
+        for (int c : {12, 8, 4, 2, 1})
+            if (c <= nsteps - n &&
+                (c <= 8 || (h->dtype == FDTD2D_F32 && h->ce_uniform && h->ch_uniform)) &&
+                pass_geometry(h, c, &lo, &hi)) {
+                nt = c;
+                break;
+            }
         if (nt) {
             rc = h->dtype == FDTD2D_F32
                      ? launch_pass<float>(h, nt, lo, hi, src_row, src_col, amps ? amps + n : nullptr)
@@ -856,7 +868,7 @@ int fdtd2d_set_option(fdtd2d_t *h, int option, long long value)
     if (!h) return FDTD2D_E_ARG;
     switch (option) {
     case FDTD2D_OPT_MAX_PASS_STEPS:
-        if (value < 0 || value > 8) return fail(h, FDTD2D_E_ARG, "pass length must be 0..8");
+        if (value < 0 || value > fdtd::STREAM_MAX_NT) return fail(h, FDTD2D_E_ARG, "pass length must be 0..12");
         h->max_nt = (int)value;
         return 0;
     case FDTD2D_OPT_BAND_ROWS:

@@ -33,8 +33,10 @@
 
 namespace fdtd {
 
-constexpr int STREAM_HC = 8;        // halo columns per strip side (>= NT, multiple of V)
-constexpr int STREAM_MAX_NT = 8;
+constexpr int STREAM_MAX_NT = 12;   // longest pass (register budget: (NT + 4) slots x 12 VGPRs)
+// halo columns per strip side: >= NT (validity shrinks one column per level from a strip
+// edge) and a multiple of 4 so that every lane's 16-byte access stays aligned
+constexpr int stream_hc(int nt) { return nt <= 4 ? 4 : (nt <= 8 ? 8 : 12); }
 
 template <class T> struct PassParams {
     const T *ez_in, *hx_in, *hy_in;
@@ -74,6 +76,19 @@ __device__ __forceinline__ double from_prev(double x)
 // One row of the strip on its way through the time levels: the registers of a slot are
 // loaded with level 0 of row r and then updated IN PLACE to level 1, 2, ... NT on the
 // following ticks, so no value is ever copied between registers.
+// First column held by a strip.  Strips advance by OW = SW - 2 HC columns and overlap by HC
+// on each side.  The LAST strip is shifted left until it ends at the grid's right edge:
+// inside the right Mur band a cell depends on columns j-2..j of the previous level, so
+// invalid data entering from a strip's left edge would advance two columns per level
+// there; with the shift that edge is a full strip width away from the band.
+template <class T, int NT> __device__ __forceinline__ int strip_x0(const PassParams<T> &p, int strip)
+{
+    constexpr int SW = 64 * Vec<T>::N, HC = stream_hc(NT), OW = SW - 2 * HC;
+    int x0 = strip * OW - HC;
+    if (strip == p.nstrips - 1) x0 = min(x0, (p.g.C - SW + 3) & ~3);
+    return x0;
+}
+
 template <class T, bool CE_ARR, bool CH_ARR> struct Slot {
     Vec<T> e, x, y;
     Vec<T> ce, ch;   // the row's coefficients ride along (only touched when arrays)
@@ -98,12 +113,13 @@ __device__ __forceinline__ void stream_body(const PassParams<T> &p, const int st
                                             const int rb)
 {
     constexpr int V = Vec<T>::N;
-    constexpr int SW = 64 * V, OW = SW - 2 * STREAM_HC;
+    constexpr int HC = stream_hc(NT);
+    constexpr int SW = 64 * V, OW = SW - 2 * HC;
     constexpr int PF = STREAM_PF;          // rows in flight ahead of level 0
     constexpr int S = NT + PF + 2;         // ring of row slots; the tick loop is unrolled S times
     const Geom g = p.g;
     const int lane = threadIdx.x;
-    const int x0 = strip * OW - STREAM_HC;
+    const int x0 = strip_x0<T, NT>(p, strip);
     const int j0 = x0 + V * lane;
     const bool ld_ok = j0 >= 0 && j0 < g.C;
     const bool st_ok = ld_ok && j0 >= strip * OW && j0 < (strip + 1) * OW;
@@ -359,7 +375,7 @@ template <class T, int NT, bool CE_ARR, bool CH_ARR>
 __global__ __launch_bounds__(64, STREAM_WPE) void k_pass(const PassParams<T> p)
 {
     constexpr int V = Vec<T>::N;
-    constexpr int SW = 64 * V, OW = SW - 2 * STREAM_HC;
+    constexpr int SW = 64 * V;
     int b = blockIdx.x;
     const int nzone = (p.zone_top + p.zone_bot) * p.zone_tiles;
     if (b < nzone) {
@@ -375,7 +391,7 @@ __global__ __launch_bounds__(64, STREAM_WPE) void k_pass(const PassParams<T> p)
     const int ra = p.band_lo + band * p.band_rows;
     const int rb = min(ra + p.band_rows, p.band_hi);
     if (ra >= rb) return;
-    const int x0 = strip * OW - STREAM_HC;
+    const int x0 = strip_x0<T, NT>(p, strip);
     // wave-uniform choice: all SW columns plain interior (5 <= j <= C-6) and the source cell
     // outside the rows/columns this wave ever touches -> mask-free body
     const bool edge = x0 < 5 || x0 + SW > p.g.C - 5;

@@ -165,8 +165,10 @@ double fdtd2d_source_amplitude(int src_kind, double t, double fc);
 int fdtd2d_sync(fdtd2d_t *h);
 
 /* Tuning knobs of fdtd2d_run (results do not depend on them, only speed):
- *   FDTD2D_OPT_MAX_PASS_STEPS  longest temporally blocked pass, 0..8 (0 = plain single steps
- *                              with the half-step kernels); default 8
+ *   FDTD2D_OPT_MAX_PASS_STEPS  longest temporally blocked pass, 0..12 (0 = plain single steps
+ *                              with the half-step kernels); default 8.  12-step passes exist
+ *                              for float32 with uniform materials only (measured slower than 8
+ *                              on 4096^2, about equal on 16384^2: profiles/r01_nt12_sweep.txt).
  *   FDTD2D_OPT_BAND_ROWS       rows per streaming band (0 = heuristic) */
 #define FDTD2D_OPT_MAX_PASS_STEPS 0
 #define FDTD2D_OPT_BAND_ROWS      1

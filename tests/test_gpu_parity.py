@@ -362,3 +362,23 @@ def test_blocked_passes_2048_vs_c_oracle(fd, onp, corc):
         got = eng.download()
     for a, b, k in zip(got, ref, ("Ez", "Hx", "Hy")):
         assert np.array_equal(a, b), k
+
+
+@pytest.mark.parametrize("cols", [225, 229, 231, 232, 233, 236, 240, 241, 247, 336, 343, 344, 350, 460])
+def test_f64_passes_strip_seams_vs_right_band(fd, onp, cols):
+    """float64 is the sharp test for dependency-cone mistakes (in float32 a wrong input ten
+    columns away drowns in rounding).  Widths put the last strip's seam at every offset
+    from the right Mur band for 4-step (OW 120) and 8-step (OW 112) float64 passes."""
+    r, n = 60, 12                      # passes 8 + 4
+    rng = np.random.default_rng(cols)
+    Ez, Hx, Hy, eps, mu = _random_state(rng, r, cols, np.float64, onp)
+    amps = rng.standard_normal(n)
+    ref = [a.copy() for a in (Ez, Hx, Hy)]
+    onp.leapfrog(*ref, eps, mu, DT, DX, n, 30, cols - 3, amps=amps)
+    with fd.Engine(r, cols, DT, DX, dtype=np.float64) as eng:
+        eng.set_materials(eps, mu)
+        eng.upload(Ez, Hx, Hy)
+        eng.run(n, 30, cols - 3, amps)
+        got = eng.download()
+    for a, b, k in zip(got, ref, ("Ez", "Hx", "Hy")):
+        assert np.array_equal(a, b), f"{k} cols={cols}: {np.argwhere(a != b)[:4]}"

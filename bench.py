@@ -166,6 +166,8 @@ def main():
     if world != args.gpus:
         sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
                  f"--nproc-per-node {args.gpus}")
+    if os.environ.get("FDTD2D_ONE_GPU"):
+        local = 0
     torch.cuda.set_device(local)
     rows = args.grid or SLAB_ROWS * world
     cols = args.cols or (args.grid if args.grid else SLAB_ROWS * world)
@@ -194,7 +196,13 @@ def main():
     # ---- N > 1: one process per GPU, row slabs, halo exchange over RCCL ---------------------
     import torch.distributed as dist
     from fdtd2d_amd.slab import SlabRunner
-    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    # FDTD2D_DIST_BACKEND=gloo + FDTD2D_ONE_GPU=1: rehearsal of this code path with several
+    # ranks on ONE GPU (halos staged through the host); never used for reported numbers.
+    backend = os.environ.get("FDTD2D_DIST_BACKEND", "nccl")
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group(backend)
     runner = SlabRunner(rows, cols, DT, DX, dtype=np.float32, device=local)
     lo, hi = runner.engine.stored_rows
     eps, mu = make_materials(fd, args.materials, rows, cols, lo, hi)
@@ -211,7 +219,7 @@ def main():
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
-    wall = torch.tensor([time.perf_counter() - t0], device="cuda")
+    wall = torch.tensor([time.perf_counter() - t0], device="cuda" if backend == "nccl" else "cpu")
     dist.all_reduce(wall, op=dist.ReduceOp.MAX)
     wall = float(wall.item())
     ok = runner.sanity()
@@ -230,7 +238,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{rows}x{cols} fp32 TE-mode, {args.materials} eps/mu, Mur-5 "
                                    f"boundary, {world} row slabs of {slab} rows, halo 8 rows of "
-                                   "Ez/Hx/Hy every 8 steps over RCCL send/recv",
+                                   f"Ez/Hx/Hy every 8 steps over {backend} send/recv",
                        "grid": [rows, cols], "materials": args.materials,
                        "per_gpu_slab": [slab, cols], "fields_finite": bool(ok)},
             "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS * world,

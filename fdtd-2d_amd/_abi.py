@@ -47,6 +47,8 @@ SIGNATURES = {
     "fdtd2d_update_e": (_i, [_vp]),
     "fdtd2d_add_point": (_i, [_vp, _i, _i, _d]),
     "fdtd2d_run": (_i, [_vp, _i, _i, _i, C.POINTER(_d)]),
+    "fdtd2d_pass_rows": (_i, [_vp, _i, _i, _i, _i, _i, C.POINTER(_d)]),
+    "fdtd2d_pass_commit": (_i, [_vp]),
     "fdtd2d_run_waveform": (_i, [_vp, _i, _i, _i, _i, _d, _ll]),
     "fdtd2d_source_amplitude": (_d, [_i, _d, _d]),
     "fdtd2d_set_option": (_i, [_vp, _i, _ll]),

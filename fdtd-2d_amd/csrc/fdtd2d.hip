@@ -52,6 +52,9 @@ struct fdtd2d {
     Range ev{0, 0}, hv{0, 0};    // global rows on which Ez / (Hx,Hy) are current
     long long step = 0;
     long long pass_launches = 0, step_launches = 0;
+    // a pass issued in pieces (fdtd2d_pass_rows) and not yet committed
+    int pend_nt = 0;
+    std::vector<Range> pend_done;
 
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -352,13 +355,14 @@ template <class T, int NT, bool CE_ARR, bool CH_ARR>
 int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
 {
     using D = fdtd::ZoneDims<NT>;
-    const int region = p.band_hi - p.band_lo;
+    const int region = std::max(0, p.band_hi - p.band_lo);
     p.nbands = (region + p.band_rows - 1) / p.band_rows;
     p.zone_tiles = (h->cols + D::WZ - 1) / D::WZ;
     // with a single strip the "last strip" slot of the launch order stays empty
     const int strip_slots = p.nstrips == 1 ? 2 : p.nstrips;
     const long long blocks = (long long)(p.zone_top + p.zone_bot) * p.zone_tiles +
                              (long long)p.nbands * strip_slots;
+    if (blocks == 0) return 0;
     hipLaunchKernelGGL((fdtd::k_pass<T, NT, CE_ARR, CH_ARR>), dim3((unsigned)blocks), dim3(64), 0,
                        h->stream, p);
     HIPCHK(h, hipGetLastError());
@@ -380,7 +384,8 @@ template <class T, int NT> int launch_pass_nt(fdtd2d *h, fdtd::PassParams<T> &p)
 
 // One pass of nt in {1,2,4,8} steps; amps = nt amplitudes or nullptr.
 template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, int src_row,
-                                   int src_col, const double *amps)
+                                   int src_col, const double *amps, bool ztop, bool zbot,
+                                   bool commit, int full_lo, int full_hi)
 {
     constexpr int V = fdtd::Vec<T>::N;
     const int OW = 64 * V - 2 * fdtd::stream_hc(nt);
@@ -406,13 +411,13 @@ template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, 
         // 2300 waves in flight (256 CUs x 2 waves x 4 SIMDs, slightly oversubscribed) and
         // bands of 32..128 rows; shorter bands pay too much pipeline fill, taller ones
         // leave CUs idle at the tail.
-        const int region = band_hi - band_lo;
+        const int region = std::max(0, band_hi - band_lo);
         const int want = std::max(1, (2304 + p.nstrips - 1) / p.nstrips);
         br = std::min(std::max(region / want, 32), 128);
     }
     p.band_rows = std::max(br, 1);
-    p.zone_top = h->top();
-    p.zone_bot = h->bottom();
+    p.zone_top = ztop;
+    p.zone_bot = zbot;
     p.src_row = amps ? src_row : -1;
     p.src_col = amps ? src_col : -1;
     for (int s = 0; s < fdtd::STREAM_MAX_NT; ++s) p.amp[s] = (amps && s < nt) ? amps[s] : 0.0;
@@ -428,10 +433,12 @@ template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, 
     default: return fail(h, FDTD2D_E_ARG, "unsupported pass length %d", nt);
     }
     if (rc) return rc;
-    h->cur ^= 1;
-    h->hcur ^= 1;
-    h->ev = h->hv = Range{h->top() ? 0 : band_lo, h->bottom() ? h->rows : band_hi};
-    h->step += nt;
+    if (commit) {
+        h->cur ^= 1;
+        h->hcur ^= 1;
+        h->ev = h->hv = Range{h->top() ? 0 : full_lo, h->bottom() ? h->rows : full_hi};
+        h->step += nt;
+    }
     return 0;
 }
 
@@ -803,6 +810,7 @@ int fdtd2d_run(fdtd2d_t *h, int nsteps, int src_row, int src_col, const double *
 {
     int rc = need_ready(h);
     if (rc) return rc;
+    if (h->pend_nt) return fail(h, FDTD2D_E_STATE, "a partial pass is pending: commit it first");
     if (nsteps < 0) return fail(h, FDTD2D_E_ARG, "nsteps < 0");
     if (amps && (src_row < 0 || src_row >= h->rows || src_col < 0 || src_col >= h->cols))
         return fail(h, FDTD2D_E_ARG, "source cell (%d,%d) outside the %dx%d grid", src_row,
@@ -819,9 +827,10 @@ int fdtd2d_run(fdtd2d_t *h, int nsteps, int src_row, int src_col, const double *
                 break;
             }
         if (nt) {
+            const double *a = amps ? amps + n : nullptr;
             rc = h->dtype == FDTD2D_F32
-                     ? launch_pass<float>(h, nt, lo, hi, src_row, src_col, amps ? amps + n : nullptr)
-                     : launch_pass<double>(h, nt, lo, hi, src_row, src_col, amps ? amps + n : nullptr);
+                     ? launch_pass<float>(h, nt, lo, hi, src_row, src_col, a, h->top(), h->bottom(), true, lo, hi)
+                     : launch_pass<double>(h, nt, lo, hi, src_row, src_col, a, h->top(), h->bottom(), true, lo, hi);
             if (rc) return rc;
             n += nt;
             continue;
@@ -831,6 +840,71 @@ int fdtd2d_run(fdtd2d_t *h, int nsteps, int src_row, int src_col, const double *
         if (amps && (rc = do_add_point(h, src_row, src_col, amps[n]))) return rc;
         ++n;
     }
+    return 0;
+}
+
+int fdtd2d_pass_rows(fdtd2d_t *h, int nt, int row_lo, int row_hi, int src_row, int src_col,
+                     const double *amps)
+{
+    int rc = need_ready(h);
+    if (rc) return rc;
+    if (h->pend_nt && h->pend_nt != nt)
+        return fail(h, FDTD2D_E_STATE, "a %d-step pass is pending; cannot add rows of a %d-step pass",
+                    h->pend_nt, nt);
+    if (nt != 1 && nt != 2 && nt != 4 && nt != 8) return fail(h, FDTD2D_E_ARG, "pass length must be 1, 2, 4 or 8");
+    int lo = 0, hi = 0;
+    if (!pass_geometry(h, nt, &lo, &hi))
+        return fail(h, FDTD2D_E_STATE, "a %d-step pass is not possible from the current state "
+                    "(rows current: Ez [%d,%d), H [%d,%d))", nt, h->ev.lo, h->ev.hi, h->hv.lo, h->hv.hi);
+    const int zo = 5 + nt;
+    const int p_lo = h->top() ? 0 : lo, p_hi = h->bottom() ? h->rows : hi;   // rows a full pass writes
+    if (row_lo < p_lo || row_hi > p_hi || row_lo >= row_hi)
+        return fail(h, FDTD2D_E_ARG, "rows [%d,%d) are outside what this pass produces, [%d,%d)",
+                    row_lo, row_hi, p_lo, p_hi);
+    // the top / bottom zone is written as a whole or not at all
+    if (h->top() && row_lo != 0 && row_lo < zo) return fail(h, FDTD2D_E_ARG, "rows cut through the top zone [0,%d)", zo);
+    if (h->top() && row_lo == 0 && row_hi < zo) return fail(h, FDTD2D_E_ARG, "rows cut through the top zone [0,%d)", zo);
+    if (h->bottom() && row_hi != h->rows && row_hi > h->rows - zo)
+        return fail(h, FDTD2D_E_ARG, "rows cut through the bottom zone [%d,%d)", h->rows - zo, h->rows);
+    if (h->bottom() && row_hi == h->rows && row_lo > h->rows - zo)
+        return fail(h, FDTD2D_E_ARG, "rows cut through the bottom zone [%d,%d)", h->rows - zo, h->rows);
+    const bool zt = h->top() && row_lo == 0, zb = h->bottom() && row_hi == h->rows;
+    const int b_lo = std::max(row_lo, lo), b_hi = std::min(row_hi, hi);
+    rc = h->dtype == FDTD2D_F32
+             ? launch_pass<float>(h, nt, b_lo, b_hi, src_row, src_col, amps, zt, zb, false, lo, hi)
+             : launch_pass<double>(h, nt, b_lo, b_hi, src_row, src_col, amps, zt, zb, false, lo, hi);
+    if (rc) return rc;
+    h->pend_nt = nt;
+    h->pend_done.push_back(Range{row_lo, row_hi});
+    return 0;
+}
+
+int fdtd2d_pass_commit(fdtd2d_t *h)
+{
+    if (!h) return FDTD2D_E_ARG;
+    if (!h->pend_nt) return fail(h, FDTD2D_E_STATE, "no partial pass is pending");
+    const int nt = h->pend_nt;
+    int lo = 0, hi = 0;
+    if (!pass_geometry(h, nt, &lo, &hi)) return fail(h, FDTD2D_E_STATE, "state changed under a pending pass");
+    const int p_lo = h->top() ? 0 : lo, p_hi = h->bottom() ? h->rows : hi;
+    // the pieces must tile [p_lo, p_hi)
+    std::sort(h->pend_done.begin(), h->pend_done.end(), [](const Range &a, const Range &b) { return a.lo < b.lo; });
+    int at = p_lo;
+    for (const Range &r : h->pend_done) {
+        if (r.lo > at) break;
+        at = std::max(at, r.hi);
+    }
+    if (at < p_hi) {
+        h->pend_nt = 0;
+        h->pend_done.clear();
+        return fail(h, FDTD2D_E_STATE, "pending pass covers rows up to %d of [%d,%d): dropped", at, p_lo, p_hi);
+    }
+    h->cur ^= 1;
+    h->hcur ^= 1;
+    h->ev = h->hv = Range{p_lo, p_hi};
+    h->step += nt;
+    h->pend_nt = 0;
+    h->pend_done.clear();
     return 0;
 }
 
@@ -898,6 +972,20 @@ int fdtd2d_halo_pack(fdtd2d_t *h, int side, void *dev_buf)
     if (!h || !dev_buf) return FDTD2D_E_ARG;
     int rc = use_device(h), first = 0;
     if (rc || (rc = halo_rows(h, side, true, &first))) return rc;
+    if (h->pend_nt) {
+        // pack the rows of the pending (not yet committed) pass: they must have been issued
+        bool ok = false;
+        for (const Range &r : h->pend_done) ok = ok || (r.lo <= first && r.hi >= first + h->halo);
+        if (!ok) return fail(h, FDTD2D_E_STATE, "rows [%d,%d) of the pending pass were not issued yet",
+                             first, first + h->halo);
+        h->cur ^= 1;
+        h->hcur ^= 1;
+        rc = h->dtype == FDTD2D_F32 ? launch_halo<float, true>(h, first, dev_buf)
+                                    : launch_halo<double, true>(h, first, dev_buf);
+        h->cur ^= 1;
+        h->hcur ^= 1;
+        return rc;
+    }
     const int r0 = h->row0, r1 = h->row0 + h->nrows;
     if (h->ev.lo > r0 || h->ev.hi < r1 || h->hv.lo > r0 || h->hv.hi < r1)
         return fail(h, FDTD2D_E_STATE, "owned rows are not current; cannot pack a halo message");

@@ -208,6 +208,20 @@ class Engine:
                                       a.ctypes.data_as(C.POINTER(C.c_double))))
         return self
 
+    def pass_rows(self, nt, row_lo, row_hi, src_row=0, src_col=0, amps=None):
+        """Issue output rows [row_lo,row_hi) of one nt-step pass on the current stream."""
+        ap = None
+        if amps is not None:
+            a = np.ascontiguousarray(amps, dtype=np.float64)
+            if a.shape[0] < nt:
+                raise ValueError("amps shorter than the pass")
+            ap = a.ctypes.data_as(C.POINTER(C.c_double))
+        self._ck(self._lib.fdtd2d_pass_rows(self._h, int(nt), int(row_lo), int(row_hi), int(src_row),
+                                            int(src_col), ap))
+
+    def pass_commit(self):
+        self._ck(self._lib.fdtd2d_pass_commit(self._h))
+
     def run_waveform(self, nsteps, kind="ricker", src_row=0, src_col=0, fc=30e9, step0=0):
         k = {"none": _abi.SRC_NONE, "ricker": _abi.SRC_RICKER,
              "sinusoidal": _abi.SRC_SINUSOIDAL}[kind]

@@ -65,7 +65,7 @@ class SlabRunner:
     per-rank engine (default: the HIP Engine)."""
 
     def __init__(self, rows, cols, dt=5e-14, dx=1e-4, dtype=np.float32, boundary="mur", device=0,
-                 halo=HALO, group=None, engine_factory=None):
+                 halo=HALO, group=None, engine_factory=None, overlap=True):
         import torch
         import torch.distributed as dist
         self.dist, self.torch = dist, torch
@@ -91,10 +91,15 @@ class SlabRunner:
         # All device work of this rank (engine kernels, pack/unpack, and -- through the
         # stream-ordering rules of torch.distributed -- the RCCL transfers) is ordered on ONE
         # side stream, so the host never has to wait for the GPU inside run().
-        self.stream = None
+        self.stream = self.edge_stream = None
         if str(self.buf_device).startswith("cuda"):
             self.stream = torch.cuda.Stream(device=self.buf_device)
+            self.edge_stream = torch.cuda.Stream(device=self.buf_device)
             self.engine.set_stream(self.stream.cuda_stream)
+        # overlap: compute the rows next to the cuts first (second stream), send them while
+        # the interior of the slab is still being computed
+        self.overlap = bool(overlap) and self.world > 1
+        self._halo_fresh = False
         if self.world > 1:
             n = 3 * self.halo * self.cols
             td = _torch_dtype(self.dtype)
@@ -152,40 +157,87 @@ class SlabRunner:
     def upload(self, Ez=None, Hx=None, Hy=None):
         """Arrays for the OWNED rows in the reference's shapes."""
         self.engine.upload(Ez, Hx, Hy)
+        self._halo_fresh = False
         return self
 
     # -- the loop ---------------------------------------------------------------------------
-    def exchange(self):
-        """Owned edge rows -> neighbours' halos (Ez, Hx, Hy; `halo` rows each way).
-        Call under `self._on_stream()`."""
-        if self.world == 1:
-            return
-        dist, eng = self.dist, self.engine
+    def _transfer(self, sides):
+        """Move the packed send buffers of `sides` to the neighbours' recv buffers.
+        nccl: enqueued behind the current stream, returns the pending works (wait() on them
+        makes the then-current stream wait; the host never blocks).  gloo: blocking, staged
+        through host memory when the buffers live on the device (tests only)."""
+        dist = self.dist
         ops, staged = [], []
-        for side, nb in ((0, self.up), (1, self.down)):
-            if nb is None:
-                continue
+        for side in sides:
             send, recv, stage = self._bufs[side]
-            eng.halo_pack(side, send.data_ptr())
-            if stage is not None:             # gloo with device buffers (tests): via host
-                eng.sync()
+            if stage is not None:
+                self.torch.cuda.synchronize()
                 stage[0].copy_(send)
                 s, r = stage
                 staged.append((recv, r))
             else:
                 s, r = send, recv
-            peer = self._global(nb)
+            peer = self._global(self.up if side == 0 else self.down)
             ops.append(dist.P2POp(dist.isend, s, peer, self.group))
             ops.append(dist.P2POp(dist.irecv, r, peer, self.group))
-        # nccl: the transfers are enqueued behind the pack kernels (current stream) and
-        # wait() makes the current stream wait for them -- no host synchronisation
-        for w in dist.batch_isend_irecv(ops):
+        works = dist.batch_isend_irecv(ops) if ops else []
+        if self.backend != "nccl":
+            for w in works:
+                w.wait()
+            for recv, r in staged:
+                recv.copy_(r)
+            if staged:
+                self.torch.cuda.synchronize()
+            works = []
+        return works
+
+    def _sides(self):
+        return [s for s, nb in ((0, self.up), (1, self.down)) if nb is not None]
+
+    def exchange(self):
+        """Owned edge rows -> neighbours' halos (Ez, Hx, Hy; `halo` rows each way).
+        Call under `self._on_stream()`."""
+        if self.world == 1:
+            return
+        eng, sides = self.engine, self._sides()
+        for side in sides:
+            eng.halo_pack(side, self._bufs[side][0].data_ptr())
+        for w in self._transfer(sides):
             w.wait()
-        for recv, r in staged:
-            recv.copy_(r)
-        for side, nb in ((0, self.up), (1, self.down)):
-            if nb is not None:
-                eng.halo_unpack(side, self._bufs[side][1].data_ptr())
+        for side in sides:
+            eng.halo_unpack(side, self._bufs[side][1].data_ptr())
+        self._halo_fresh = True
+
+    def _cycle_overlapped(self, n, src_row, src_col, amps):
+        """One pass of n = halo steps with the exchange for the NEXT pass hidden behind the
+        interior: (edge stream) rows next to the cuts -> pack -> send/recv;  (main stream)
+        everything else;  then commit and unpack.  Needs fresh halos, leaves fresh halos."""
+        torch, eng, sides = self.torch, self.engine, self._sides()
+        r0, r1, h = self.r0, self.r1, self.halo
+        main, edge = self.stream, self.edge_stream
+        if edge is not None:
+            edge.wait_stream(main)
+            eng.set_stream(edge.cuda_stream)
+        ctx = torch.cuda.stream(edge) if edge is not None else self._on_stream()
+        with ctx:
+            for side in sides:
+                lo, hi = (r0, r0 + h) if side == 0 else (r1 - h, r1)
+                eng.pass_rows(n, lo, hi, src_row, src_col, amps)
+                eng.halo_pack(side, self._bufs[side][0].data_ptr())
+            works = self._transfer(sides)
+        if edge is not None:
+            eng.set_stream(main.cuda_stream)
+        lo = r0 + h if self.up is not None else 0
+        hi = r1 - h if self.down is not None else self.rows
+        eng.pass_rows(n, lo, hi, src_row, src_col, amps)
+        for w in works:
+            w.wait()                       # main stream waits for the transfers
+        if edge is not None:
+            main.wait_stream(edge)
+        eng.pass_commit()
+        for side in sides:
+            eng.halo_unpack(side, self._bufs[side][1].data_ptr())
+        self._halo_fresh = True
 
     def _on_stream(self):
         import contextlib
@@ -198,11 +250,19 @@ class SlabRunner:
             if amps.shape[0] < nsteps:
                 raise ValueError("amps shorter than nsteps")
         done = 0
+        can_overlap = self.overlap and (self.r1 - self.r0) >= 2 * self.halo + 1 and \
+            hasattr(self.engine, "pass_rows")
         with self._on_stream():
             while done < nsteps:
                 n = nsteps - done if self.world == 1 else min(self.halo, nsteps - done)
-                self.exchange()
-                self.engine.run(n, src_row, src_col, None if amps is None else amps[done:done + n])
+                a = None if amps is None else amps[done:done + n]
+                if self.world > 1 and not self._halo_fresh:
+                    self.exchange()
+                if can_overlap and n == self.halo:
+                    self._cycle_overlapped(n, src_row, src_col, a)
+                else:
+                    self.engine.run(n, src_row, src_col, a)
+                    self._halo_fresh = False
                 done += n
         self.steps_done += nsteps
         return self

@@ -155,6 +155,17 @@ int fdtd2d_add_point(fdtd2d_t *h, int row, int col, double amp);
  * neighbours, nsteps must not exceed the halo validity left. */
 int fdtd2d_run(fdtd2d_t *h, int nsteps, int src_row, int src_col, const double *amps);
 
+/* One temporally blocked pass of nt in {1,2,4,8} steps issued in pieces, so that a caller can
+ * compute the rows its neighbours wait for first, send them, and overlap the transfer with
+ * the rest: fdtd2d_pass_rows() launches the pass for output rows [row_lo,row_hi) only (reading
+ * the current fields, writing the other buffer set; pieces may go to different streams via
+ * fdtd2d_set_stream); fdtd2d_pass_commit() makes the new set current once the pieces tile
+ * everything a full pass writes.  Between the two, fdtd2d_halo_pack() packs from the NEW
+ * set.  amps = nt amplitudes (the same for every piece) or NULL. */
+int fdtd2d_pass_rows(fdtd2d_t *h, int nt, int row_lo, int row_hi, int src_row, int src_col,
+                     const double *amps);
+int fdtd2d_pass_commit(fdtd2d_t *h);
+
 /* Same with the waveform evaluated by the library at t = (step0+n)*dt. */
 int fdtd2d_run_waveform(fdtd2d_t *h, int nsteps, int src_kind, int src_row, int src_col,
                         double fc, long long step0);

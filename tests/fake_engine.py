@@ -91,6 +91,17 @@ class FakeEngine:
         a, b = self._rows(side, True)
         n = self.halo * self.cols
         buf = _view(ptr, 3 * n, self.dtype)
+        if self.pending is not None:
+            assert any(lo <= a and hi >= b for lo, hi in self.pending["rows"]), "edge rows not issued"
+            cur = (self.Ez, self.Hx, self.Hy)
+            self.Ez, self.Hx, self.Hy = self.pending["new"]
+            try:
+                self.pending, keep = None, self.pending
+                self.halo_pack(side, ptr)
+            finally:
+                self.pending = keep
+                self.Ez, self.Hx, self.Hy = cur
+            return
         # Hx has cols-1 columns and Hy rows-1 rows in the reference layout; the message
         # carries `cols` per row like the device engine (missing entries are zeros)
         hx = np.zeros((self.halo, self.cols), self.dtype)
@@ -113,6 +124,34 @@ class FakeEngine:
             self.valid[0] = a
         else:
             self.valid[1] = b
+
+    # -- a pass issued in pieces (Engine.pass_rows / pass_commit) ---------------------------
+    pending = None
+
+    def pass_rows(self, nt, row_lo, row_hi, src_row=0, src_col=0, amps=None):
+        if self.pending is None:
+            keep = (self.Ez, self.Hx, self.Hy, list(self.valid))
+            self.Ez, self.Hx, self.Hy = self.Ez.copy(), self.Hx.copy(), self.Hy.copy()
+            self.run(nt, src_row, src_col, amps)
+            new = (self.Ez, self.Hx, self.Hy)
+            self.Ez, self.Hx, self.Hy, self.valid = keep
+            self.pending = dict(new=new, rows=[], nt=nt, amps=None if amps is None else np.array(amps[:nt]))
+        p = self.pending
+        assert p["nt"] == nt and (amps is None) == (p["amps"] is None)
+        assert amps is None or np.array_equal(p["amps"], np.asarray(amps[:nt])), "pieces disagree on amps"
+        p["rows"].append((row_lo, row_hi))
+
+    def pass_commit(self):
+        p = self.pending
+        assert p is not None, "no pending pass"
+        at = self.row0
+        for lo, hi in sorted(p["rows"]):
+            assert lo <= at, f"rows [{at},{lo}) of the pending pass were never issued"
+            at = max(at, hi)
+        assert at >= self.row0 + self.nrows
+        self.Ez, self.Hx, self.Hy = p["new"]
+        self.valid = [self.row0, self.row0 + self.nrows]
+        self.pending = None
 
     def run(self, nsteps, src_row=0, src_col=0, amps=None):
         lo = 0 if self.row0 == 0 else self.valid[0]

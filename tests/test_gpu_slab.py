@@ -14,13 +14,14 @@ from dist_harness import run_job
 DT, DX = 5e-14, 1e-4
 
 
-@pytest.mark.parametrize("world,shape,dtype,materials", [
-    (2, (200, 300), "float32", "array"),
-    (3, (180, 520), "float32", "array"),
-    (2, (128, 256), "float64", "array"),
-    (2, (160, 700), "float32", "uniform"),
+@pytest.mark.parametrize("world,shape,dtype,materials,overlap", [
+    (2, (200, 300), "float32", "array", True),
+    (3, (180, 520), "float32", "array", True),
+    (2, (128, 256), "float64", "array", True),
+    (2, (160, 700), "float32", "uniform", True),
+    (3, (180, 520), "float32", "array", False),
 ])
-def test_gpu_slabs_match_single_engine_and_oracle(tmp_path, world, shape, dtype, materials):
+def test_gpu_slabs_match_single_engine_and_oracle(tmp_path, world, shape, dtype, materials, overlap):
     import fdtd2d_amd as fd
     from oracle import fdtd_numpy as onp
     r, c = shape
@@ -36,7 +37,7 @@ def test_gpu_slabs_match_single_engine_and_oracle(tmp_path, world, shape, dtype,
     np.savez(path, **st)
     src = (r // world, c // 2)               # on the first cut
     job = dict(engine="hip", shape=shape, dtype=dtype, dt=DT, dx=DX, state=path, src=src,
-               chunks=[n], materials=materials)
+               chunks=[n], materials=materials, overlap=overlap)
     got = run_job(world, job, str(tmp_path))
     dt_ = np.dtype(dtype)
     with fd.Engine(r, c, DT, DX, dtype=dt_) as eng:

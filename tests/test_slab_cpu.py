@@ -41,12 +41,13 @@ def _state(tmp_path, r, c, seed, nsteps, vary_mu=False):
 @pytest.mark.parametrize("world,shape,src", [(2, (40, 24), (19, 5)), (2, (41, 30), (20, 29)),
                                              (3, (66, 20), (22, 3)), (3, (70, 25), (1, 1))])
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
-def test_slab_runner_matches_single_domain_oracle(tmp_path, world, shape, src, dtype):
+@pytest.mark.parametrize("overlap", [True, False])
+def test_slab_runner_matches_single_domain_oracle(tmp_path, world, shape, src, dtype, overlap):
     """27 steps in chunks (8+8+3, then 8): source on a cut / in a halo / on the frame."""
     r, c = shape
     st, path = _state(str(tmp_path), r, c, 11 * r + c, 27, vary_mu=True)
     job = dict(engine="fake", shape=shape, dtype=dtype, dt=DT, dx=DX, state=path, src=src,
-               chunks=[19, 8], materials="array")
+               chunks=[19, 8], materials="array", overlap=overlap)
     got = run_job(world, job, str(tmp_path))
     dt_ = np.dtype(dtype)
     ref = [st[k].astype(dt_) for k in ("Ez", "Hx", "Hy")]

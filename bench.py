@@ -130,6 +130,19 @@ def time_single(fd, rows, cols, steps, warmup, materials, device):
     return res
 
 
+def measured_traffic(rows, cols, materials, steps_per_launch):
+    """HBM bytes per launch from the committed PMC profile of this exact configuration
+    (profiles/r01_traffic.json), or None: counters cannot be read from inside the bench."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        e = t.get(f"{rows}x{cols}:{materials}")
+        if e and abs(e["steps_per_launch"] - steps_per_launch) < 1e-9:
+            return e["bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
 def roofline_block(cells, steps, r):
     """Per-launch algorithmic rate of the dominant kernel."""
     if r["pass_launches"]:
@@ -188,6 +201,8 @@ def main():
                        "grid": [rows, cols], "materials": args.materials},
             "roofline": roofline_block(cells, args.steps, r),
         }
+        rl = res["roofline"]
+        rl["traffic"] = measured_traffic(rows, cols, args.materials, args.steps / rl["launches"])
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(rows)
         print(json.dumps(res))

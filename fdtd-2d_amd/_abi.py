@@ -56,6 +56,8 @@ SIGNATURES = {
     "fdtd2d_halo_bytes": (_ll, [_vp]),
     "fdtd2d_halo_pack": (_i, [_vp, _i, _vp]),
     "fdtd2d_halo_unpack": (_i, [_vp, _i, _vp]),
+    "fdtd2d_snapshot_index": (_i, [_vp, _d, _d, _i, _vp]),
+    "fdtd2d_reduce": (_i, [_vp, _i, C.POINTER(_d), C.POINTER(_d)]),
     "fdtd2d_timer_start": (_i, [_vp]),
     "fdtd2d_timer_stop": (_i, [_vp, C.POINTER(C.c_float)]),
     "fdtd2d_bytes_per_cell_step": (_i, [_vp]),

@@ -66,6 +66,62 @@ def sinusoidal(rows, cols, x_pos, y_pos, t, fc):
     return src
 
 
+# ---- snapshots (python-src/main.py:153-179) ----------------------------------------------------
+
+def snapshot_indices(Ez, vmax=20, vmin=-20):
+    """LUT index matplotlib derives for `cmap((clip(Ez) - vmin)/(vmax - vmin))`, in Ez's dtype
+    (main.py:155,167-168).  Host twin of Engine.snapshot_index()."""
+    x = (np.clip(Ez, vmin, vmax) - vmin) / (vmax - vmin)
+    y = x * 256
+    idx = y.astype(int)
+    idx[y == 256] = 255
+    return np.clip(idx, 0, 255).astype(np.uint8)
+
+
+def eps_background(eps):
+    """uint8 gray level behind the field plot (main.py:157-165)."""
+    eps = np.asarray(eps)
+    eps_min = EPS0
+    eps_max = np.max(eps)
+    if eps_max == eps_min:
+        return np.full(eps.shape, 255, dtype=np.uint8)
+    frac = (eps - eps_min) / (eps_max - eps_min)
+    return ((1 - frac) * 127 + 128).astype(np.uint8)
+
+
+_snap_table = None
+
+
+def snapshot_table():
+    """(256, 256, 3) uint8: final pixel for (colour index, background gray) -- the seismic
+    colour map at alpha 0.7 over the gray level (main.py:167-174), tabulated once."""
+    global _snap_table
+    if _snap_table is None:
+        import matplotlib
+        lut = matplotlib.colormaps["seismic"](np.arange(256))[:, :3]            # (256, 3) float64
+        gray = np.arange(256, dtype=np.float64)[None, :, None] / 255
+        alpha = 0.7
+        _snap_table = ((lut[:, None, :] * alpha + gray * (1 - alpha)) * 255).astype(np.uint8)
+    return _snap_table
+
+
+def render_snapshot(indices, eps_gray):
+    """RGB image (uint8) from colour indices and the eps background."""
+    return snapshot_table()[indices, eps_gray]
+
+
+def capture_snapshot(Ez, eps, path, vmax=20, vmin=-20):
+    """Drop-in for main.py:153-179: seismic colour map of clip(Ez) at alpha 0.7 over the eps
+    background, written as PNG.  Ez may be a host array or an Engine (then the colour index is
+    computed on the device and only one byte per cell is downloaded)."""
+    from PIL import Image
+    idx = Ez.snapshot_index(vmin, vmax, 1) if isinstance(Ez, Engine) else snapshot_indices(np.asarray(Ez), vmax, vmin)
+    img = render_snapshot(idx, eps_background(eps))
+    if path is not None:
+        Image.fromarray(img).save(path)
+    return img
+
+
 def courant_number(eps, mu, dt, dx):
     """fdtd.py:25-26."""
     c = 1 / np.sqrt(np.min(eps) * np.min(mu))

@@ -58,6 +58,8 @@ struct fdtd2d {
 
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t t0 = nullptr, t1 = nullptr;
+    void *scratch = nullptr;     // device scratch for snapshots / reduction partials
+    size_t scratch_bytes = 0;
     std::string err;
 
     bool top() const { return row0 == 0; }
@@ -654,6 +656,7 @@ void fdtd2d_destroy(fdtd2d_t *h)
         if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
         for (void *p : {h->ez[0], h->ez[1], h->hxb[0], h->hxb[1], h->hyb[0], h->hyb[1], h->ce, h->ch})
             if (p) (void)hipFree(p);
+        if (h->scratch) (void)hipFree(h->scratch);
         if (h->t0) (void)hipEventDestroy(h->t0);
         if (h->t1) (void)hipEventDestroy(h->t1);
         if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -1010,6 +1013,78 @@ int fdtd2d_halo_unpack(fdtd2d_t *h, int side, const void *dev_buf)
         if (h->ev.hi >= h->row0 + h->nrows) h->ev.hi = first + h->halo;
         if (h->hv.hi >= h->row0 + h->nrows) h->hv.hi = first + h->halo;
     }
+    return 0;
+}
+
+static int need_scratch(fdtd2d *h, size_t bytes)
+{
+    if (h->scratch_bytes >= bytes) return 0;
+    if (h->scratch) (void)hipFree(h->scratch);
+    h->scratch = nullptr;
+    h->scratch_bytes = 0;
+    if (hipMalloc(&h->scratch, bytes) != hipSuccess) return fail(h, FDTD2D_E_NOMEM, "scratch allocation failed");
+    h->scratch_bytes = bytes;
+    return 0;
+}
+
+int fdtd2d_snapshot_index(fdtd2d_t *h, double vmin, double vmax, int stride, unsigned char *out)
+{
+    if (!h || !out) return FDTD2D_E_ARG;
+    if (stride < 1 || !(vmax > vmin)) return fail(h, FDTD2D_E_ARG, "need stride >= 1 and vmax > vmin");
+    int rc = use_device(h);
+    if (rc) return rc;
+    const int r0 = h->row0, r1 = h->row0 + h->nrows;
+    if (h->ev.lo > r0 || h->ev.hi < r1) return fail(h, FDTD2D_E_STATE, "owned rows of Ez are not current");
+    const int first = ((r0 + stride - 1) / stride) * stride;          // global rows i with i % stride == 0
+    const int nro = first < r1 ? (r1 - 1 - first) / stride + 1 : 0;
+    const int nco = (h->cols - 1) / stride + 1;
+    if (nro == 0) return 0;
+    const size_t bytes = (size_t)nro * nco;
+    if ((rc = need_scratch(h, bytes))) return rc;
+    dim3 grid((unsigned)((nco + 255) / 256), (unsigned)nro);
+    if (h->dtype == FDTD2D_F32)
+        hipLaunchKernelGGL((fdtd::k_snapshot<float>), grid, dim3(256), 0, h->stream, (const float *)h->ez[h->cur],
+                           (unsigned char *)h->scratch, h->geom(), first, nro, nco, stride, (float)vmin,
+                           (float)vmax, (float)(vmax - vmin));
+    else
+        hipLaunchKernelGGL((fdtd::k_snapshot<double>), grid, dim3(256), 0, h->stream, (const double *)h->ez[h->cur],
+                           (unsigned char *)h->scratch, h->geom(), first, nro, nco, stride, vmin, vmax,
+                           vmax - vmin);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(out, h->scratch, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int fdtd2d_reduce(fdtd2d_t *h, int field, double *sum_sq, double *max_abs)
+{
+    if (!h) return FDTD2D_E_ARG;
+    int rc = use_device(h);
+    if (rc) return rc;
+    const void *f = fdtd2d_device_ptr(h, field);
+    if (!f) return fail(h, FDTD2D_E_ARG, "unknown field %d", field);
+    const int r0 = h->row0, r1 = h->row0 + h->nrows;
+    const Range &v = field == FDTD2D_FIELD_EZ ? h->ev : h->hv;
+    if (v.lo > r0 || v.hi < r1) return fail(h, FDTD2D_E_STATE, "owned rows are not current");
+    const int blocks = 1024;
+    if ((rc = need_scratch(h, (size_t)blocks * 2 * sizeof(double)))) return rc;
+    if (h->dtype == FDTD2D_F32)
+        hipLaunchKernelGGL((fdtd::k_reduce<float>), dim3(blocks), dim3(256), 0, h->stream, (const float *)f,
+                           (double *)h->scratch, h->geom(), r0, h->nrows, h->cols);
+    else
+        hipLaunchKernelGGL((fdtd::k_reduce<double>), dim3(blocks), dim3(256), 0, h->stream, (const double *)f,
+                           (double *)h->scratch, h->geom(), r0, h->nrows, h->cols);
+    HIPCHK(h, hipGetLastError());
+    std::vector<double> part((size_t)blocks * 2);
+    HIPCHK(h, hipMemcpyAsync(part.data(), h->scratch, part.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    double s = 0, m = 0;
+    for (int b = 0; b < blocks; ++b) {
+        s += part[2 * b];
+        m = std::max(m, part[2 * b + 1]);
+    }
+    if (sum_sq) *sum_sq = s;
+    if (max_abs) *max_abs = m;
     return 0;
 }
 

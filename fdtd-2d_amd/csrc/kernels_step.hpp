@@ -190,6 +190,61 @@ __global__ __launch_bounds__(256) void k_coef(T *__restrict__ a, size_t n, T dt,
     }
 }
 
+// ---- snapshot: Ez -> colour-map index, decimated (main.py:155,167-168) -----------------------
+// idx = trunc(256 * (clip(Ez, vmin, vmax) - vmin) / (vmax - vmin)), 256 -> 255: the LUT index
+// matplotlib's Colormap.__call__ derives for the reference's `cmap((normed - vmin)/(vmax - vmin))`,
+// computed in T like NumPy does for an array of type T.  One byte per sampled cell leaves the
+// device instead of sizeof(T) bytes per cell.
+template <class T>
+__global__ __launch_bounds__(256) void k_snapshot(const T *__restrict__ ez, unsigned char *__restrict__ out,
+                                                  Geom g, int row_first, int nrows_out, int ncols_out,
+                                                  int stride, T vmin, T vmax, T range)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    if (q >= ncols_out || r >= nrows_out) return;
+    T v = ez[at(g, row_first + r * stride, q * stride)];
+    v = v < vmin ? vmin : v;
+    v = v > vmax ? vmax : v;
+    const T y = ((v - vmin) / range) * T(256);
+    int idx = (int)y;
+    idx = (y == T(256)) ? 255 : idx;
+    idx = idx < 0 ? 0 : (idx > 255 ? 255 : idx);
+    out[(size_t)r * ncols_out + q] = (unsigned char)idx;
+}
+
+// ---- reductions over the owned rows: sum of squares and max |.| of one field ------------------
+// Per-block partials (double) are written to `part`; the host adds them (blocks <= 1024).
+template <class T>
+__global__ __launch_bounds__(256) void k_reduce(const T *__restrict__ f, double *__restrict__ part,
+                                                Geom g, int row_first, int nrows, int ncols)
+{
+    __shared__ double ssum[256], smax[256];
+    double s = 0, m = 0;
+    const size_t n = (size_t)nrows * ncols;
+    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (size_t)gridDim.x * 256) {
+        const int i = row_first + (int)(t / ncols), j = (int)(t % ncols);
+        const double v = (double)f[at(g, i, j)];
+        s += v * v;
+        const double a = v < 0 ? -v : v;
+        m = a > m ? a : m;
+    }
+    ssum[threadIdx.x] = s;
+    smax[threadIdx.x] = m;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            ssum[threadIdx.x] += ssum[threadIdx.x + w];
+            smax[threadIdx.x] = smax[threadIdx.x] > smax[threadIdx.x + w] ? smax[threadIdx.x] : smax[threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        part[2 * blockIdx.x] = ssum[0];
+        part[2 * blockIdx.x + 1] = smax[0];
+    }
+}
+
 // ---- halo rows <-> contiguous message (3 fields x nrows x C) ---------------------------------
 template <class T, bool PACK>
 __global__ __launch_bounds__(256) void k_halo(T *__restrict__ f0, T *__restrict__ f1,

@@ -256,6 +256,26 @@ class Engine:
     def halo_unpack(self, side: int, dev_ptr: int):
         self._ck(self._lib.fdtd2d_halo_unpack(self._h, int(side), dev_ptr))
 
+    # -- consumers of the fields next to the loop ---------------------------------------------
+    def snapshot_index(self, vmin, vmax, stride=1):
+        """uint8 colour-map indices of Ez (owned rows whose global index is a multiple of
+        `stride`, every stride-th column), computed and decimated on the device."""
+        r0, r1 = self.owned_rows
+        first = -(-r0 // stride) * stride
+        nro = (r1 - 1 - first) // stride + 1 if first < r1 else 0
+        out = np.empty((nro, (self.cols - 1) // stride + 1), np.uint8)
+        if nro:
+            self._ck(self._lib.fdtd2d_snapshot_index(self._h, float(vmin), float(vmax), int(stride),
+                                                     out.ctypes.data))
+        return out
+
+    def reduce(self, field="Ez"):
+        """(sum of squares, max |.|) of a field over the owned rows, reduced on the device."""
+        f = {"Ez": _abi.FIELD_EZ, "Hx": _abi.FIELD_HX, "Hy": _abi.FIELD_HY}[field]
+        s, m = C.c_double(), C.c_double()
+        self._ck(self._lib.fdtd2d_reduce(self._h, f, C.byref(s), C.byref(m)))
+        return float(s.value), float(m.value)
+
     def timer_start(self):
         self._ck(self._lib.fdtd2d_timer_start(self._h))
 

@@ -198,6 +198,20 @@ int fdtd2d_halo_pack(fdtd2d_t *h, int side, void *dev_buf);
  * current.  Both sides that have a neighbour must be unpacked to restore validity. */
 int fdtd2d_halo_unpack(fdtd2d_t *h, int side, const void *dev_buf);
 
+/* ---- consumers of Ez next to the loop ---------------------- */
+
+/* Device-side first half of capture_snapshot (main.py:153-179): clip Ez to [vmin,vmax], map
+ * to the 0..255 colour-map index exactly as `cmap((normed - vmin)/(vmax - vmin))` does for an
+ * array of the engine's type, keep every `stride`-th row and column (global indices that are
+ * multiples of stride), and copy the bytes to `out` (row-major, ceil(cols/stride) per row,
+ * owned rows only).  The host applies the colour table (fdtd2d_amd.capture_snapshot).
+ * Synchronous. */
+int fdtd2d_snapshot_index(fdtd2d_t *h, double vmin, double vmax, int stride, unsigned char *out);
+
+/* Sum of squares and max |.| of one field over the owned rows (float64 accumulation).
+ * Either output may be NULL.  Synchronous. */
+int fdtd2d_reduce(fdtd2d_t *h, int field, double *sum_sq, double *max_abs);
+
 /* ---- measurement --------------------------------------------------------------- */
 
 /* HIP events on the handle's stream. stop returns elapsed milliseconds (syncs). */

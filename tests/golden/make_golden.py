@@ -147,6 +147,34 @@ def main():
         eps_vac=e[0, 0], mu_vac=m[0, 0],
         grid_shapes=np.array([a.shape for a in gz]),
         grid_dtype=str(gz[0].dtype))
+    # N2: material_init(path, ...) -- grayscale structure image -> eps (main.py:108-123).
+    # The image is drawn here (a bus waveguide and a ring, white background, black = core);
+    # the reference's own asset python-src/assets/example_structure.png is not in its repo.
+    from PIL import Image, ImageDraw
+    img = Image.new("L", (120, 96), 255)
+    d = ImageDraw.Draw(img)
+    d.line([(0, 18), (119, 18)], fill=0, width=5)
+    d.ellipse([30, 30, 90, 90], outline=0, width=4)
+    d.rectangle([100, 60, 110, 80], fill=128)
+    png = os.path.join(OUT, "structure_120x96.png")
+    img.save(png)
+    for (rr, cc, bp) in ((64, 72, 10.0), (96, 120, 4.0)):
+        e, m = ref.material_init(png, rr, cc, bp)
+        np.savez_compressed(os.path.join(OUT, f"n2_material_{rr}x{cc}.npz"), eps=e, mu=m,
+                            rows=rr, cols=cc, black_point=bp)
+
+    # N1: capture_snapshot (main.py:153-179) on a mid-run field with a non-uniform eps map
+    g3 = np.load(os.path.join(OUT, "g3_disk_64x80.npz"))
+    for tag, Ezs in (("f64", g3["Ez_f64_400"]), ("f32", g3["Ez_f32_400"])):
+        path = os.path.join(tempfile.mkdtemp(prefix="fdtd_snap_"), "s.png")
+        ref.capture_snapshot(Ezs, g3["eps"], path, 1e-3, -1e-3)
+        rgb = np.array(Image.open(path))
+        path2 = path.replace("s.png", "u.png")
+        ref.capture_snapshot(Ezs, np.full_like(g3["eps"], 8.85418e-12), path2, 0.2, -0.2)
+        rgb_u = np.array(Image.open(path2))
+        np.savez_compressed(os.path.join(OUT, f"n1_snapshot_{tag}.npz"), rgb=rgb, rgb_uniform=rgb_u,
+                            vmax=1e-3, vmin=-1e-3, vmax_u=0.2, vmin_u=-0.2)
+
     print("golden vectors written to", OUT)
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):

@@ -1,0 +1,79 @@
+"""GPU: device-side consumers of Ez next to the loop."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+DT, DX, FC = 5e-14, 1e-4, 30e9
+
+
+@pytest.mark.parametrize("tag,dtype", [("f64", np.float64), ("f32", np.float32)])
+def test_device_snapshot_equals_reference_png(golden_dir, tag, dtype):
+    """Engine state = the golden mid-run field; the device-computed colour indices rendered
+    through the host table give the reference's PNG pixels exactly."""
+    import fdtd2d_amd as fd
+    g3 = np.load(os.path.join(golden_dir, "g3_disk_64x80.npz"))
+    g = np.load(os.path.join(golden_dir, f"n1_snapshot_{tag}.npz"))
+    Ez, Hx, Hy = (g3[f"{k}_{tag}_400"] for k in ("Ez", "Hx", "Hy"))
+    with fd.Engine(64, 80, DT, DX, dtype=dtype) as eng:
+        eng.set_materials(g3["eps"].astype(dtype), np.full((64, 80), fd.MU0, dtype))
+        eng.upload(Ez, Hx, Hy)
+        img = fd.capture_snapshot(eng, g3["eps"], None, float(g["vmax"]), float(g["vmin"]))
+        assert np.array_equal(img, g["rgb"])
+        idx = eng.snapshot_index(-0.2, 0.2, 1)
+        assert np.array_equal(idx, fd.snapshot_indices(Ez, 0.2, -0.2))
+        for stride in (2, 3, 7):
+            dec = eng.snapshot_index(-0.2, 0.2, stride)
+            assert np.array_equal(dec, idx[::stride, ::stride])
+
+
+def test_snapshot_cadence_in_run_fdtd_matches_reference_loop(golden_dir):
+    """on_frame fires after step i when i % (nsteps // nframes) == 0, as fdtd.py:36-38."""
+    import fdtd2d_amd as fd
+    from oracle import fdtd_numpy as onp
+    seen = []
+    Ez, Hx, Hy = fd.run_fdtd(48, 56, DT, DX, 50, dtype=np.float64, nframes=10,
+                             on_frame=lambda i, E: seen.append((i, E.copy())))
+    assert [i for i, _ in seen] == list(range(0, 50, 5))
+    ref = onp.grid_zeros(48, 56)
+    eps, mu = onp.vacuum_materials(48, 56)
+    for i in range(50):
+        onp.leapfrog(*ref, eps, mu, DT, DX, 1, 24, 28, step0=i)
+        if i % 5 == 0:
+            assert np.array_equal(seen[i // 5][1], ref[0]), i
+    assert np.array_equal(Ez, ref[0])
+
+
+def test_sinusoidal_source_run(golden_dir):
+    """N3: the CW source of main.py:190-195 through run_fdtd, against the oracle."""
+    import fdtd2d_amd as fd
+    from oracle import fdtd_numpy as onp
+    n = 64
+    Ez, Hx, Hy = fd.run_fdtd(64, 64, DT, DX, n, source=("sinusoidal", 20, 30, FC), dtype=np.float32)
+    ref = onp.grid_zeros(64, 64, np.float32)
+    eps, mu = onp.vacuum_materials(64, 64, np.float32)
+    amps = [onp.sinusoidal_amplitude(i * DT, FC) for i in range(n)]
+    onp.leapfrog(*ref, eps, mu, DT, DX, n, 20, 30, amps=amps)
+    assert np.abs(ref[0]).max() > 0.1
+    for a, b in zip((Ez, Hx, Hy), ref):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_device_reductions(dtype):
+    """N4: sum of squares / max |.| reduced on the device (float64 accumulation)."""
+    import fdtd2d_amd as fd
+    rng = np.random.default_rng(1)
+    r, c = 300, 517
+    Ez = rng.standard_normal((r, c)).astype(dtype)
+    Hx = rng.standard_normal((r, c - 1)).astype(dtype)
+    Hy = rng.standard_normal((r - 1, c)).astype(dtype)
+    with fd.Engine(r, c, DT, DX, dtype=dtype) as eng:
+        eng.set_materials()
+        eng.upload(Ez, Hx, Hy)
+        for name, a in (("Ez", Ez), ("Hx", Hx), ("Hy", Hy)):
+            s, m = eng.reduce(name)
+            assert m == np.abs(a).max()
+            assert s == pytest.approx(np.sum(a.astype(np.float64) ** 2), rel=1e-12)

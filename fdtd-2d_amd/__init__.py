@@ -4,7 +4,7 @@ python-src/fdtd.py).  Import it as ``fdtd2d_amd`` (a directory name with '-' is 
 identifier; ``fdtd2d_amd/__init__.py`` at the repo root points here)."""
 from ._abi import Fdtd2dError, LIB_PATH  # noqa: F401
 from .api import (EPS0, MU0, capture_snapshot, courant_number, grid_init, material_init,  # noqa: F401
-                  render_snapshot, ricker, ricker_amplitude, run_fdtd, sinusoidal,
+                  pml_profiles, render_snapshot, ricker, ricker_amplitude, run_fdtd, sinusoidal,
                   sinusoidal_amplitude, snapshot_indices, eps_background, step, update_Ez,
                   update_Hx_Hy)
 from .engine import Engine  # noqa: F401
@@ -12,4 +12,4 @@ from .engine import Engine  # noqa: F401
 __all__ = ["Engine", "Fdtd2dError", "EPS0", "MU0", "grid_init", "material_init", "ricker",
            "sinusoidal", "ricker_amplitude", "sinusoidal_amplitude", "courant_number",
            "update_Hx_Hy", "update_Ez", "step", "run_fdtd", "capture_snapshot", "render_snapshot",
-           "snapshot_indices", "eps_background"]
+           "snapshot_indices", "eps_background", "pml_profiles"]

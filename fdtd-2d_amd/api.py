@@ -66,6 +66,25 @@ def sinusoidal(rows, cols, x_pos, y_pos, t, fc):
     return src
 
 
+# ---- absorbing layer for boundary="pml" (build-defined; grading as python-src/fdfd.py:16-30) -----
+
+def pml_profiles(rows, cols, courant00, L=40, m=3, R0=1e-6, dtype=np.float64):
+    """Loss factors a = (1-s)/(1+s), b = 1/(1+s) of the split-field PML, as eight 1-D arrays:
+    rows {ahr, bhr (Hx, half positions), aer, ber (Ez)}, columns {ahc, bhc (Hy), aec, bec}.
+    s(d) = s_max (d/L)^m with s_max = (m+1) ln(1/R0) courant00 / (4 L), d = depth in cells;
+    L = 40 and m = 3 are the defaults of the reference's frequency-domain PML."""
+    smax = (m + 1) * np.log(1.0 / R0) * courant00 / (4.0 * L)
+    out = {}
+    for tag, n in (("r", rows), ("c", cols)):
+        pos = np.arange(n, dtype=np.float64)
+        for kind, p in (("e", pos), ("h", pos + 0.5)):
+            d = np.maximum(0.0, np.maximum(L - p, p - (n - 1 - L)))
+            s = smax * (d / L) ** m
+            out["a" + kind + tag] = ((1 - s) / (1 + s)).astype(dtype)
+            out["b" + kind + tag] = (1 / (1 + s)).astype(dtype)
+    return out
+
+
 # ---- snapshots (python-src/main.py:153-179) ----------------------------------------------------
 
 def snapshot_indices(Ez, vmax=20, vmin=-20):
@@ -246,6 +265,10 @@ def run_fdtd(rows=200, cols=200, dt=5e-14, dx=1e-4, nsteps=1000, eps=None, mu=No
     assert courant <= 1.0, f"Courant stability condition not met: {courant} > 1.0"
     with Engine(rows, cols, dt, dx, dtype=dtype, boundary=boundary, device=device) as eng:
         eng.set_materials(eps_h, mu_h)
+        if boundary == "pml":
+            e00 = eps_h if np.isscalar(eps_h) else np.asarray(eps_h)[0, 0]
+            m00 = mu_h if np.isscalar(mu_h) else np.asarray(mu_h)[0, 0]
+            eng.set_pml(courant00=(1 / np.sqrt(float(e00) * float(m00)) * dt) / dx)
         amps, sr, sc = None, 0, 0
         if source is not None:
             kind, sr, sc, fc = source

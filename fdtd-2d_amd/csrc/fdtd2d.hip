@@ -15,6 +15,7 @@
 
 #include "kernels_step.hpp"
 #include "kernels_stream.hpp"
+#include "kernels_pml.hpp"
 
 using fdtd::Geom;
 
@@ -44,6 +45,10 @@ struct fdtd2d {
     void *hxb[2] = {nullptr, nullptr}, *hyb[2] = {nullptr, nullptr};
     int hcur = 0;                // hxb[hcur], hyb[hcur] are the current Hx, Hy
     void *ce = nullptr, *ch = nullptr;    // coefficient arrays (nullptr when uniform)
+    void *ezx = nullptr;                  // PML only: the x-part of the split Ez
+    void *pml = nullptr;                  // PML only: 4 row + 4 column factor arrays, back to back
+    bool have_pml = false;
+    int nfields() const { return boundary == FDTD2D_BOUNDARY_PML ? 4 : 3; }
     bool have_mat = false, ce_uniform = true, ch_uniform = true;
     double ce_u = 0, ch_u = 0;   // uniform coefficients, already rounded to T
     double k_mur = 0;            // Mur factor, already rounded to T
@@ -200,6 +205,7 @@ int zero_fields(fdtd2d *h)
 {
     for (void *p : {h->ez[0], h->ez[1], h->hxb[0], h->hxb[1], h->hyb[0], h->hyb[1]})
         HIPCHK(h, hipMemsetAsync(p, 0, h->field_bytes + 256, h->stream));
+    if (h->ezx) HIPCHK(h, hipMemsetAsync(h->ezx, 0, h->field_bytes + 256, h->stream));
     h->cur = 0;
     h->hcur = 0;
     h->ev = h->hv = Range{h->store_lo(), h->store_hi()};
@@ -208,6 +214,14 @@ int zero_fields(fdtd2d *h)
 }
 
 // ---- launches --------------------------------------------------------------------------
+
+template <class T> fdtd::PmlFactors<T> pml_factors(const fdtd2d *h)
+{
+    const T *b = (const T *)h->pml;
+    const size_t R = h->rows, C = h->cols;
+    return fdtd::PmlFactors<T>{b, b + R, b + 2 * R, b + 3 * R, b + 4 * R, b + 4 * R + C, b + 4 * R + 2 * C,
+                               b + 4 * R + 3 * C};
+}
 
 template <class T> int launch_h(fdtd2d *h, int lo, int hi)
 {
@@ -218,6 +232,18 @@ template <class T> int launch_h(fdtd2d *h, int lo, int hi)
     dim3 grid((unsigned)((h->cols - 1 + 64 * V - 1) / (64 * V)),
               (unsigned)((hi - lo + 4 * RPT - 1) / (4 * RPT)));
     const T *ez = (const T *)h->ez[h->cur];
+    if (h->boundary == FDTD2D_BOUNDARY_PML) {
+        const fdtd::PmlFactors<T> f = pml_factors<T>(h);
+        if (h->ch_uniform)
+            hipLaunchKernelGGL((fdtd::k_update_h_pml<T, false, RPT>), grid, block, 0, h->stream, ez,
+                               (T *)h->hx(), (T *)h->hy(), (const T *)nullptr, (T)h->ch_u, f, g, lo, hi);
+        else
+            hipLaunchKernelGGL((fdtd::k_update_h_pml<T, true, RPT>), grid, block, 0, h->stream, ez,
+                               (T *)h->hx(), (T *)h->hy(), (const T *)h->ch, (T)0, f, g, lo, hi);
+        HIPCHK(h, hipGetLastError());
+        h->step_launches++;
+        return 0;
+    }
     if (h->ch_uniform)
         hipLaunchKernelGGL((fdtd::k_update_h<T, false, RPT>), grid, block, 0, h->stream, ez,
                            (T *)h->hx(), (T *)h->hy(), (const T *)nullptr, (T)h->ch_u, g, lo, hi);
@@ -240,6 +266,15 @@ template <class T, bool CE_ARR> int launch_e_impl(fdtd2d *h, int lo, int hi)
     dim3 block(64, 4);
     dim3 grid((unsigned)((h->cols + 64 * V - 1) / (64 * V)),
               (unsigned)((hi - lo + 4 * RPT - 1) / (4 * RPT)));
+    if (h->boundary == FDTD2D_BOUNDARY_PML) {
+        hipLaunchKernelGGL((fdtd::k_update_e_pml<T, CE_ARR, RPT>), grid, block, 0, h->stream, ez_old,
+                           ez_new, (T *)h->ezx, (const T *)h->hx(), (const T *)h->hy(), ce, ce_u,
+                           pml_factors<T>(h), g, lo, hi);
+        HIPCHK(h, hipGetLastError());
+        h->cur ^= 1;
+        h->step_launches++;
+        return 0;
+    }
     hipLaunchKernelGGL((fdtd::k_update_e<T, CE_ARR, RPT>), grid, block, 0, h->stream, ez_old,
                        ez_new, (const T *)h->hx(), (const T *)h->hy(), ce, ce_u, g, lo, hi);
     HIPCHK(h, hipGetLastError());
@@ -282,6 +317,8 @@ int need_ready(fdtd2d *h)
     if (!h) return FDTD2D_E_ARG;
     if (!h->have_mat)
         return fail(h, FDTD2D_E_STATE, "materials not set: call fdtd2d_set_materials first");
+    if (h->boundary == FDTD2D_BOUNDARY_PML && !h->have_pml)
+        return fail(h, FDTD2D_E_STATE, "PML factors not set: call fdtd2d_set_pml first");
     return use_device(h);
 }
 
@@ -488,8 +525,9 @@ int create_impl(fdtd2d_t **out, int rows, int cols, int row0, int nrows, int hal
                     "grid %dx%d is below the 11x11 minimum of the 5-px Mur band", rows, cols);
     if (dtype != FDTD2D_F32 && dtype != FDTD2D_F64)
         return fail(nullptr, FDTD2D_E_ARG, "dtype must be FDTD2D_F32 or FDTD2D_F64");
-    if (boundary != FDTD2D_BOUNDARY_NONE && boundary != FDTD2D_BOUNDARY_MUR5)
-        return fail(nullptr, FDTD2D_E_ARG, "boundary %d is not available in this build", boundary);
+    if (boundary != FDTD2D_BOUNDARY_NONE && boundary != FDTD2D_BOUNDARY_MUR5 &&
+        boundary != FDTD2D_BOUNDARY_PML)
+        return fail(nullptr, FDTD2D_E_ARG, "unknown boundary %d", boundary);
     if (!(dt > 0) || !(dx > 0)) return fail(nullptr, FDTD2D_E_ARG, "dt and dx must be positive");
     if (row0 < 0 || nrows <= 0 || row0 + nrows > rows || halo < 0)
         return fail(nullptr, FDTD2D_E_ARG, "slab [%d,%d) does not fit a %d-row grid", row0,
@@ -544,6 +582,11 @@ int create_impl(fdtd2d_t **out, int rows, int cols, int row0, int nrows, int hal
         // +256 B guard: the last lane of a row may look one vector past the row end
         if (hipMalloc(p, h->field_bytes + 256) != hipSuccess)
             return bail(fail(h, FDTD2D_E_NOMEM, "hipMalloc of %zu bytes failed", h->field_bytes));
+    }
+    if (boundary == FDTD2D_BOUNDARY_PML) {
+        const size_t fb = (size_t)(h->rows + h->cols) * 4 * h->esz;
+        if (hipMalloc(&h->ezx, h->field_bytes + 256) != hipSuccess || hipMalloc(&h->pml, fb) != hipSuccess)
+            return bail(fail(h, FDTD2D_E_NOMEM, "hipMalloc of the PML arrays failed"));
     }
     if (const char *e2 = std::getenv("FDTD2D_BAND_ROWS")) h->stream_band_rows = std::atoi(e2);
     if (const char *e2 = std::getenv("FDTD2D_MAX_NT")) h->max_nt = std::atoi(e2);
@@ -620,8 +663,15 @@ int halo_rows(fdtd2d *h, int side, bool pack, int *first)
 
 template <class T, bool PACK> int launch_halo(fdtd2d *h, int first, void *buf)
 {
-    const size_t n = (size_t)3 * h->halo * h->cols;
+    const size_t n = (size_t)h->nfields() * h->halo * h->cols;
     const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 2048);
+    if (h->boundary == FDTD2D_BOUNDARY_PML) {
+        hipLaunchKernelGGL((fdtd::k_halo4<T, PACK>), dim3(blocks), dim3(256), 0, h->stream,
+                           (T *)h->ez[h->cur], (T *)h->ezx, (T *)h->hx(), (T *)h->hy(), (T *)buf, h->geom(),
+                           first, h->halo);
+        HIPCHK(h, hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL((fdtd::k_halo<T, PACK>), dim3(blocks), dim3(256), 0, h->stream,
                        (T *)h->ez[h->cur], (T *)h->hx(), (T *)h->hy(), (T *)buf, h->geom(), first,
                        h->halo);
@@ -654,7 +704,7 @@ void fdtd2d_destroy(fdtd2d_t *h)
     if (!h) return;
     if (hipSetDevice(h->device) == hipSuccess) {
         if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
-        for (void *p : {h->ez[0], h->ez[1], h->hxb[0], h->hxb[1], h->hyb[0], h->hyb[1], h->ce, h->ch})
+        for (void *p : {h->ez[0], h->ez[1], h->hxb[0], h->hxb[1], h->hyb[0], h->hyb[1], h->ce, h->ch, h->ezx, h->pml})
             if (p) (void)hipFree(p);
         if (h->scratch) (void)hipFree(h->scratch);
         if (h->t0) (void)hipEventDestroy(h->t0);
@@ -735,6 +785,34 @@ int fdtd2d_set_materials_uniform(fdtd2d_t *h, double eps, double mu)
     }
     h->have_mat = true;
     return 0;
+}
+
+int fdtd2d_set_pml(fdtd2d_t *h, const void *row_factors, const void *col_factors, int host_dtype)
+{
+    if (!h) return FDTD2D_E_ARG;
+    if (h->boundary != FDTD2D_BOUNDARY_PML) return fail(h, FDTD2D_E_STATE, "handle was not created with FDTD2D_BOUNDARY_PML");
+    if (!row_factors || !col_factors) return fail(h, FDTD2D_E_ARG, "factor arrays must not be NULL");
+    if (host_dtype != h->dtype) return fail(h, FDTD2D_E_ARG, "PML factors must have the engine's dtype");
+    int rc = use_device(h);
+    if (rc) return rc;
+    char *d = (char *)h->pml;
+    HIPCHK(h, hipMemcpy(d, row_factors, (size_t)4 * h->rows * h->esz, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(d + (size_t)4 * h->rows * h->esz, col_factors, (size_t)4 * h->cols * h->esz,
+                        hipMemcpyHostToDevice));
+    h->have_pml = true;
+    return 0;
+}
+
+int fdtd2d_transfer_ezx(fdtd2d_t *h, void *host, int host_dtype, int to_device)
+{
+    if (!h || !host) return FDTD2D_E_ARG;
+    if (!h->ezx) return fail(h, FDTD2D_E_STATE, "no split field: handle was not created with FDTD2D_BOUNDARY_PML");
+    if (host_dtype != FDTD2D_F32 && host_dtype != FDTD2D_F64) return fail(h, FDTD2D_E_ARG, "bad host_dtype");
+    int rc = use_device(h);
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return to_device ? copy_in(h, h->ezx, host, host_dtype, h->halo, h->nrows, h->cols)
+                     : copy_out(h, h->ezx, host, host_dtype, h->halo, h->nrows, h->cols);
 }
 
 double fdtd2d_courant(const fdtd2d_t *h)
@@ -967,7 +1045,7 @@ int fdtd2d_sync(fdtd2d_t *h)
 
 long long fdtd2d_halo_bytes(const fdtd2d_t *h)
 {
-    return h ? 3LL * h->halo * h->cols * (long long)h->esz : FDTD2D_E_ARG;
+    return h ? (long long)h->nfields() * h->halo * h->cols * (long long)h->esz : FDTD2D_E_ARG;
 }
 
 int fdtd2d_halo_pack(fdtd2d_t *h, int side, void *dev_buf)

@@ -123,6 +123,31 @@ class Engine:
                                                 _code(e.dtype), cptr, int(bool(allow_uniform))))
         return self
 
+    def set_pml(self, L=40, m=3, R0=1e-6, courant00=None):
+        """boundary="pml" only: build the split-field PML's factor arrays (pml_profiles) for
+        the global grid and hand them to the engine.  courant00 = Courant number of the
+        [0,0] material cell (default: vacuum)."""
+        from .api import pml_profiles, EPS0, MU0
+        if courant00 is None:
+            courant00 = (1 / np.sqrt(EPS0 * MU0) * self.dt) / self.dx
+        P = pml_profiles(self.rows, self.cols, courant00, L, m, R0, self.dtype)
+        rowf = np.ascontiguousarray(np.concatenate([P["ahr"], P["bhr"], P["aer"], P["ber"]]))
+        colf = np.ascontiguousarray(np.concatenate([P["ahc"], P["bhc"], P["aec"], P["bec"]]))
+        self._ck(self._lib.fdtd2d_set_pml(self._h, rowf.ctypes.data, colf.ctypes.data, _code(self.dtype)))
+        return self
+
+    def upload_ezx(self, Ezx):
+        a = np.ascontiguousarray(Ezx, dtype=self.dtype)
+        if a.shape != (self.nrows, self.cols):
+            raise ValueError(f"Ezx must have shape {(self.nrows, self.cols)}")
+        self._ck(self._lib.fdtd2d_transfer_ezx(self._h, a.ctypes.data, _code(a.dtype), 1))
+        return self
+
+    def download_ezx(self):
+        a = np.empty((self.nrows, self.cols), self.dtype)
+        self._ck(self._lib.fdtd2d_transfer_ezx(self._h, a.ctypes.data, _code(a.dtype), 0))
+        return a
+
     def courant(self) -> float:
         return float(self._lib.fdtd2d_courant(self._h))
 

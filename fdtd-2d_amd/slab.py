@@ -98,10 +98,11 @@ class SlabRunner:
             self.engine.set_stream(self.stream.cuda_stream)
         # overlap: compute the rows next to the cuts first (second stream), send them while
         # the interior of the slab is still being computed
-        self.overlap = bool(overlap) and self.world > 1
+        self.boundary = boundary
+        self.overlap = bool(overlap) and self.world > 1 and boundary in ("mur", "mur5")
         self._halo_fresh = False
         if self.world > 1:
-            n = 3 * self.halo * self.cols
+            n = self.engine.halo_bytes // self.dtype.itemsize    # 3 fields (4 with the PML's Ezx)
             td = _torch_dtype(self.dtype)
             for side, nb in ((0, self.up), (1, self.down)):
                 if nb is None:
@@ -112,7 +113,6 @@ class SlabRunner:
                 if self.backend == "gloo" and send.is_cuda:   # gloo moves host memory only
                     stage = (torch.empty(n, dtype=td).pin_memory(), torch.empty(n, dtype=td).pin_memory())
                 self._bufs[side] = (send, recv, stage)
-            assert self.engine.halo_bytes == n * self.dtype.itemsize
         self.steps_done = 0
 
     # -- setup ----------------------------------------------------------------------------
@@ -138,6 +138,8 @@ class SlabRunner:
         else:
             self.engine.set_materials(e_s, m_s, corner=(float(c[0]), float(c[1])),
                                       allow_uniform=allow_uniform)
+        if self.boundary == "pml":
+            self.engine.set_pml(courant00=(1 / np.sqrt(float(c[0]) * float(c[1])) * self.dt) / self.dx)
         return self
 
     def _global(self, group_rank):

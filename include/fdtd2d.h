@@ -122,6 +122,15 @@ int fdtd2d_set_materials(fdtd2d_t *h, const void *eps, const void *mu, int host_
 /* material_init(None, ...) path (main.py:103-106) and any other constant medium. */
 int fdtd2d_set_materials_uniform(fdtd2d_t *h, double eps, double mu);
 
+/* FDTD2D_BOUNDARY_PML only (BASELINE config 5; build-defined, the reference has no
+ * time-domain PML): Berenger split-field layer.  row_factors = 4*rows values {ahr, bhr, aer,
+ * ber}, col_factors = 4*cols values {ahc, bhc, aec, bec} (a = (1-s)/(1+s), b = 1/(1+s), 1
+ * outside the layer; see oracle/pml_numpy.py / fdtd2d_amd.pml_profiles), in the engine's
+ * dtype, for the GLOBAL grid (slabs index them by global row).  Ez is stored as total field
+ * plus its x-part Ezx; fdtd2d_transfer_ezx moves the owned rows of Ezx (rows x cols). */
+int fdtd2d_set_pml(fdtd2d_t *h, const void *row_factors, const void *col_factors, int host_dtype);
+int fdtd2d_transfer_ezx(fdtd2d_t *h, void *host, int host_dtype, int to_device);
+
 /* Courant number c*dt/dx from the smallest eps and mu given so far (fdtd.py:25-26). */
 double fdtd2d_courant(const fdtd2d_t *h);
 
@@ -187,7 +196,7 @@ int fdtd2d_set_option(fdtd2d_t *h, int option, long long value);
 
 /* ---- row-slab halo exchange (transport is the caller's: RCCL via torch.distributed) -- */
 
-/* Bytes of one halo message: 3 fields x halo rows x cols elements. */
+/* Bytes of one halo message: 3 fields (4 with the PML's Ezx) x halo rows x cols elements. */
 long long fdtd2d_halo_bytes(const fdtd2d_t *h);
 
 /* Pack the `halo` owned rows nearest to side (0 = top/lower row index, 1 = bottom)

@@ -51,3 +51,29 @@ def test_gpu_slabs_match_single_engine_and_oracle(tmp_path, world, shape, dtype,
     for a, b, c_, k in zip(got, one, ref, ("Ez", "Hx", "Hy")):
         assert np.array_equal(a, b), f"{k}: slabs differ from the single engine"
         assert np.array_equal(a, c_), f"{k}: slabs differ from the oracle"
+
+
+def test_gpu_slabs_pml_match_single_engine(tmp_path):
+    """boundary="pml" over 2 slabs (4-field halo messages, single-step kernels consuming the
+    halo) equals the single-engine PML run bit for bit."""
+    import fdtd2d_amd as fd
+    from oracle import fdtd_numpy as onp
+    r, c, n = 220, 260, 21
+    rng = np.random.default_rng(5)
+    st = dict(Ez=np.zeros((r, c)), Hx=np.zeros((r, c - 1)), Hy=np.zeros((r - 1, c)),
+              eps=onp.EPS0 * rng.uniform(1, 3, (r, c)), mu=onp.MU0 * np.ones((r, c)),
+              amps=rng.standard_normal(n))
+    st["eps"][0, 0] = onp.EPS0
+    path = os.path.join(str(tmp_path), "state.npz")
+    np.savez(path, **st)
+    job = dict(engine="hip", shape=(r, c), dtype="float32", dt=DT, dx=DX, state=path, src=(110, 130),
+               chunks=[n], materials="array", boundary="pml")
+    got = run_job(2, job, str(tmp_path))
+    with fd.Engine(r, c, DT, DX, dtype=np.float32, boundary="pml") as eng:
+        eng.set_materials(st["eps"].astype(np.float32), st["mu"].astype(np.float32))
+        eng.set_pml()
+        eng.run(n, 110, 130, st["amps"])
+        one = eng.download()
+    assert np.abs(one[0]).max() > 0
+    for a, b, k in zip(got, one, ("Ez", "Hx", "Hy")):
+        assert np.array_equal(a, b), k

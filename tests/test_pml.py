@@ -1,0 +1,86 @@
+"""Absorbing layer for BASELINE config 5 (boundary="pml").  PARITY UNPINNED: the reference has
+no time-domain PML; these tests pin the device path to the build's own CPU restatement
+(oracle/pml_numpy.py) bit for bit and check the physics against the reference's Mur frame."""
+import numpy as np
+import pytest
+
+DT, DX, FC = 5e-14, 1e-4, 30e9
+
+
+def test_profiles_product_and_oracle_agree():
+    import fdtd2d_amd as fd
+    from oracle import pml_numpy as pm
+    for dtype in (np.float32, np.float64):
+        a = fd.pml_profiles(130, 97, 0.15, 40, 3, 1e-6, dtype)
+        b = pm.profiles(130, 97, 0.15, 40, 3, 1e-6, dtype)
+        assert set(a) == set(b)
+        for k in a:
+            assert np.array_equal(a[k], b[k]), k
+        assert np.all(a["aer"][40:-40] == 1) and np.all(a["ber"][40:-40] == 1) and a["aer"][0] < 1
+
+
+def test_split_field_layer_absorbs_better_than_mur_cpu():
+    """Oracle-level physics: residual energy in the centre window long after the pulse has left,
+    summed over steps 2000..2800, is at least 10x lower with the PML than with the Mur frame."""
+    from oracle import fdtd_numpy as onp
+    from oracle import pml_numpy as pm
+    R = C = 160
+    eps, mu = onp.vacuum_materials(R, C)
+    P = pm.profiles(R, C, onp.courant_number(eps, mu, DT, DX), L=40)
+    amps = [onp.ricker_amplitude(i * DT, FC) for i in range(2800)]
+    Em, Hxm, Hym = onp.grid_zeros(R, C)
+    Ep, Hxp, Hyp = onp.grid_zeros(R, C)
+    Ezx = np.zeros_like(Ep)
+    res_m = res_p = 0.0
+    for i in range(2800):
+        onp.leapfrog(Em, Hxm, Hym, eps, mu, DT, DX, 1, R // 2, C // 2, amps=[amps[i]])
+        pm.leapfrog(Ep, Ezx, Hxp, Hyp, eps, mu, DT, DX, 1, R // 2, C // 2, [amps[i]], P)
+        if i >= 2000 and i % 100 == 0:
+            w = slice(50, 110)
+            res_m += float((Em[w, w] ** 2).sum())
+            res_p += float((Ep[w, w] ** 2).sum())
+    assert res_p * 10 < res_m, (res_p, res_m)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("shape,L", [((96, 130), 20), ((200, 301), 40)])
+def test_device_pml_matches_oracle(dtype, shape, L):
+    import fdtd2d_amd as fd
+    from oracle import fdtd_numpy as onp
+    from oracle import pml_numpy as pm
+    r, c = shape
+    rng = np.random.default_rng(r)
+    Ez = rng.standard_normal((r, c)).astype(dtype)
+    Ezx = (0.3 * rng.standard_normal((r, c))).astype(dtype)
+    Hx = (rng.standard_normal((r, c - 1)) * 1e-3).astype(dtype)
+    Hy = (rng.standard_normal((r - 1, c)) * 1e-3).astype(dtype)
+    eps = (onp.EPS0 * rng.uniform(1, 4, (r, c))).astype(dtype)
+    mu = np.full((r, c), onp.MU0).astype(dtype)
+    S = 0.15
+    P = pm.profiles(r, c, S, L=L, dtype=dtype)
+    n = 20
+    amps = rng.standard_normal(n)
+    ref = [a.copy() for a in (Ez, Ezx, Hx, Hy)]
+    pm.leapfrog(*ref, eps, mu, DT, DX, n, r // 2, c // 3, amps, P)
+    with fd.Engine(r, c, DT, DX, dtype=dtype, boundary="pml") as eng:
+        eng.set_materials(eps, mu).set_pml(L=L, courant00=S)
+        eng.upload(Ez, Hx, Hy).upload_ezx(Ezx)
+        eng.run(n, r // 2, c // 3, amps)
+        got = eng.download()
+        gx = eng.download_ezx()
+    for a, b, k in zip((got[0], gx, got[1], got[2]), ref, ("Ez", "Ezx", "Hx", "Hy")):
+        assert np.array_equal(a, b), k
+
+
+@pytest.mark.gpu
+def test_device_pml_run_fdtd_absorbs():
+    """run_fdtd(boundary="pml"): after the pulse has left a 256x256 grid the field is far
+    smaller than with the Mur frame (same source, same steps)."""
+    import fdtd2d_amd as fd
+    n = 2600
+    Ep, _, _ = fd.run_fdtd(256, 256, DT, DX, n, boundary="pml", dtype=np.float32)
+    Em, _, _ = fd.run_fdtd(256, 256, DT, DX, n, boundary="mur", dtype=np.float32)
+    w = slice(60, 196)
+    assert np.isfinite(Ep).all()
+    assert float((Ep[w, w].astype(np.float64) ** 2).sum()) * 10 < float((Em[w, w].astype(np.float64) ** 2).sum())

@@ -100,16 +100,18 @@ def make_materials(fd, kind, rows, cols, r0=0, r1=None):
     raise ValueError(kind)
 
 
-def time_single(fd, rows, cols, steps, warmup, materials, device):
+def time_single(fd, rows, cols, steps, warmup, materials, device, boundary="mur"):
     """One whole-grid engine on one GPU.  Returns dict(wall_s, event_ms, launches, ...)."""
     import torch
-    eng = fd.Engine(rows, cols, DT, DX, dtype=np.float32, device=device)
+    eng = fd.Engine(rows, cols, DT, DX, dtype=np.float32, device=device, boundary=boundary)
     eps, mu = make_materials(fd, materials, rows, cols)
     if eps is None:
         eng.set_materials()
     else:
         eng.set_materials(eps, mu, allow_uniform=(materials != "array"))
     del eps, mu
+    if boundary == "pml":
+        eng.set_pml()
     sr, sc = rows // 2, cols // 2
     eng.run(warmup, sr, sc, amplitudes(fd, 0, warmup)).sync()
     amps = amplitudes(fd, warmup, steps)
@@ -167,6 +169,8 @@ def main():
     ap.add_argument("--grid", type=int, default=0, help="rows (default 4096 per GPU)")
     ap.add_argument("--cols", type=int, default=0, help="columns (default 4096*gpus)")
     ap.add_argument("--materials", choices=["uniform", "array", "ring"], default="uniform")
+    ap.add_argument("--boundary", choices=["mur", "pml"], default="mur",
+                    help="mur = the reference's 5-px Mur frame; pml = the build-defined split-field PML")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -187,22 +191,24 @@ def main():
     cells = rows * cols
 
     if world == 1:
-        r = time_single(fd, rows, cols, args.steps, args.warmup, args.materials, local)
+        r = time_single(fd, rows, cols, args.steps, args.warmup, args.materials, local, args.boundary)
         value = cells * args.steps / r["wall_s"] / 1e6
         res = {
             "metric": "Mcell-steps/s", "value": round(value, 1), "unit": "Mcell-steps/s",
             "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(r["wall_s"] * 1e3 / args.steps, 5), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{rows}x{cols} fp32 TE-mode, {args.materials} eps/mu, Mur-5 "
-                                   "boundary, ricker point source at the centre"
-                                   + (" (BASELINE configs[1])" if (rows, cols, args.materials) ==
-                                      (4096, 4096, "uniform") else ""),
-                       "grid": [rows, cols], "materials": args.materials},
+            "config": {"workload": f"{rows}x{cols} fp32 TE-mode, {args.materials} eps/mu, "
+                                   + ("Mur-5" if args.boundary == "mur" else "split-field PML (40 cells)")
+                                   + " boundary, ricker point source at the centre"
+                                   + (" (BASELINE configs[1])" if (rows, cols, args.materials, args.boundary) ==
+                                      (4096, 4096, "uniform", "mur") else ""),
+                       "grid": [rows, cols], "materials": args.materials, "boundary": args.boundary},
             "roofline": roofline_block(cells, args.steps, r),
         }
         rl = res["roofline"]
-        rl["traffic"] = measured_traffic(rows, cols, args.materials, args.steps / rl["launches"])
+        if args.boundary == "mur":
+            rl["traffic"] = measured_traffic(rows, cols, args.materials, args.steps / rl["launches"])
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(rows)
         print(json.dumps(res))
@@ -218,7 +224,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     else:
         dist.init_process_group(backend)
-    runner = SlabRunner(rows, cols, DT, DX, dtype=np.float32, device=local)
+    runner = SlabRunner(rows, cols, DT, DX, dtype=np.float32, device=local, boundary=args.boundary)
     lo, hi = runner.engine.stored_rows
     eps, mu = make_materials(fd, args.materials, rows, cols, lo, hi)
     runner.set_materials(eps, mu, allow_uniform=(args.materials != "array"))
@@ -241,7 +247,7 @@ def main():
     slab = runner.engine.nrows
     runner.close()
     if rank == 0:
-        single = time_single(fd, slab, cols, min(args.steps, 96), 16, args.materials, local)
+        single = time_single(fd, slab, cols, min(args.steps, 96), 16, args.materials, local, args.boundary)
         single_v = slab * cols * min(args.steps, 96) / single["wall_s"] / 1e6
         value = cells * args.steps / wall / 1e6
         bpc = single["bpc"]
@@ -251,7 +257,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(wall * 1e3 / args.steps, 5), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{rows}x{cols} fp32 TE-mode, {args.materials} eps/mu, Mur-5 "
+            "config": {"workload": f"{rows}x{cols} fp32 TE-mode, {args.materials} eps/mu, {args.boundary} "
                                    f"boundary, {world} row slabs of {slab} rows, halo 8 rows of "
                                    f"Ez/Hx/Hy every 8 steps over {backend} send/recv",
                        "grid": [rows, cols], "materials": args.materials,

@@ -39,7 +39,7 @@ SIGNATURES = {
     "fdtd2d_set_stream": (_i, [_vp, _vp]),
     "fdtd2d_set_materials": (_i, [_vp, _vp, _vp, _i, C.POINTER(_d), _i]),
     "fdtd2d_set_materials_uniform": (_i, [_vp, _d, _d]),
-    "fdtd2d_set_pml": (_i, [_vp, _vp, _vp, _i]),
+    "fdtd2d_set_pml": (_i, [_vp, _vp, _vp, _i, _i]),
     "fdtd2d_transfer_ezx": (_i, [_vp, _vp, _i, _i]),
     "fdtd2d_courant": (_d, [_vp]),
     "fdtd2d_upload": (_i, [_vp, _vp, _vp, _vp, _i]),

@@ -45,9 +45,10 @@ struct fdtd2d {
     void *hxb[2] = {nullptr, nullptr}, *hyb[2] = {nullptr, nullptr};
     int hcur = 0;                // hxb[hcur], hyb[hcur] are the current Hx, Hy
     void *ce = nullptr, *ch = nullptr;    // coefficient arrays (nullptr when uniform)
-    void *ezx = nullptr;                  // PML only: the x-part of the split Ez
+    void *ezxb[2] = {nullptr, nullptr};   // PML only: the x-part of the split Ez (set follows hcur)
     void *pml = nullptr;                  // PML only: 4 row + 4 column factor arrays, back to back
     bool have_pml = false;
+    int pml_L = 0;
     int nfields() const { return boundary == FDTD2D_BOUNDARY_PML ? 4 : 3; }
     bool have_mat = false, ce_uniform = true, ch_uniform = true;
     double ce_u = 0, ch_u = 0;   // uniform coefficients, already rounded to T
@@ -73,6 +74,7 @@ struct fdtd2d {
     int store_lo() const { return std::max(0, row0 - halo); }
     int store_hi() const { return std::min(rows, row0 + nrows + halo); }
     Geom geom() const { return Geom{rows, cols, row_base(), pitch}; }
+    void *ezx() const { return ezxb[hcur]; }
     void *hx() const { return hxb[hcur]; }
     void *hy() const { return hyb[hcur]; }
     int stream_band_rows = 0;    // 0 = heuristic (FDTD2D_BAND_ROWS overrides)
@@ -205,7 +207,8 @@ int zero_fields(fdtd2d *h)
 {
     for (void *p : {h->ez[0], h->ez[1], h->hxb[0], h->hxb[1], h->hyb[0], h->hyb[1]})
         HIPCHK(h, hipMemsetAsync(p, 0, h->field_bytes + 256, h->stream));
-    if (h->ezx) HIPCHK(h, hipMemsetAsync(h->ezx, 0, h->field_bytes + 256, h->stream));
+    for (void *p : {h->ezxb[0], h->ezxb[1]})
+        if (p) HIPCHK(h, hipMemsetAsync(p, 0, h->field_bytes + 256, h->stream));
     h->cur = 0;
     h->hcur = 0;
     h->ev = h->hv = Range{h->store_lo(), h->store_hi()};
@@ -220,7 +223,7 @@ template <class T> fdtd::PmlFactors<T> pml_factors(const fdtd2d *h)
     const T *b = (const T *)h->pml;
     const size_t R = h->rows, C = h->cols;
     return fdtd::PmlFactors<T>{b, b + R, b + 2 * R, b + 3 * R, b + 4 * R, b + 4 * R + C, b + 4 * R + 2 * C,
-                               b + 4 * R + 3 * C};
+                               b + 4 * R + 3 * C, h->pml_L, h->rows, h->cols};
 }
 
 template <class T> int launch_h(fdtd2d *h, int lo, int hi)
@@ -268,7 +271,7 @@ template <class T, bool CE_ARR> int launch_e_impl(fdtd2d *h, int lo, int hi)
               (unsigned)((hi - lo + 4 * RPT - 1) / (4 * RPT)));
     if (h->boundary == FDTD2D_BOUNDARY_PML) {
         hipLaunchKernelGGL((fdtd::k_update_e_pml<T, CE_ARR, RPT>), grid, block, 0, h->stream, ez_old,
-                           ez_new, (T *)h->ezx, (const T *)h->hx(), (const T *)h->hy(), ce, ce_u,
+                           ez_new, (T *)h->ezx(), (const T *)h->hx(), (const T *)h->hy(), ce, ce_u,
                            pml_factors<T>(h), g, lo, hi);
         HIPCHK(h, hipGetLastError());
         h->cur ^= 1;
@@ -369,6 +372,19 @@ int do_add_point(fdtd2d *h, int row, int col, double amp)
 // Can a pass of nt steps run from the current state?  Fills the row range of the bulk.
 bool pass_geometry(const fdtd2d *h, int nt, int *band_lo, int *band_hi)
 {
+    if (h->boundary == FDTD2D_BOUNDARY_PML) {
+        // k_pass_pml: 8-step passes, uniform mu, bands over all rows (no zones)
+        if (nt != 8 || nt > h->max_nt || !h->ch_uniform || !h->have_pml) return false;
+        if (h->rows < 64 || h->cols < 64) return false;
+        const int a = std::max(h->ev.lo, h->hv.lo), b = std::min(h->ev.hi, h->hv.hi);
+        const int lo = h->top() ? 0 : a + nt, hi = h->bottom() ? h->rows : b - nt;
+        if (h->top() && a > 0) return false;
+        if (h->bottom() && b < h->rows) return false;
+        if (hi - lo < 1 || lo > h->row0 || hi < h->row0 + h->nrows) return false;
+        *band_lo = lo;
+        *band_hi = hi;
+        return true;
+    }
     if (h->boundary != FDTD2D_BOUNDARY_MUR5 || nt < 1 || nt > h->max_nt) return false;
     const int zo = 5 + nt, zr = zo + nt + 1;
     if (h->rows < 2 * zr || h->cols < 16) return false;   // small grids use the single-step path
@@ -461,6 +477,24 @@ template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, 
     p.src_col = amps ? src_col : -1;
     for (int s = 0; s < fdtd::STREAM_MAX_NT; ++s) p.amp[s] = (amps && s < nt) ? amps[s] : 0.0;
     int rc;
+    if (h->boundary == FDTD2D_BOUNDARY_PML) {
+        p.zone_top = p.zone_bot = 0;
+        p.zone_tiles = 0;
+        const int region = std::max(0, p.band_hi - p.band_lo);
+        p.nbands = (region + p.band_rows - 1) / p.band_rows;
+        const int strip_slots = p.nstrips == 1 ? 2 : p.nstrips;
+        const long long blocks = (long long)p.nbands * strip_slots;
+        fdtd::PmlPass<T> q{pml_factors<T>(h), (const T *)h->ezxb[h->hcur], (T *)h->ezxb[h->hcur ^ 1]};
+        if (blocks > 0) {
+            if (h->ce_uniform)
+                hipLaunchKernelGGL((fdtd::k_pass_pml<T, false>), dim3((unsigned)blocks), dim3(64), 0, h->stream, p, q);
+            else
+                hipLaunchKernelGGL((fdtd::k_pass_pml<T, true>), dim3((unsigned)blocks), dim3(64), 0, h->stream, p, q);
+            HIPCHK(h, hipGetLastError());
+            h->pass_launches++;
+        }
+        rc = 0;
+    } else
     switch (nt) {
     case 12:
         if constexpr (sizeof(T) == 4) { rc = launch_pass_nt<T, 12>(h, p); break; }
@@ -585,7 +619,8 @@ int create_impl(fdtd2d_t **out, int rows, int cols, int row0, int nrows, int hal
     }
     if (boundary == FDTD2D_BOUNDARY_PML) {
         const size_t fb = (size_t)(h->rows + h->cols) * 4 * h->esz;
-        if (hipMalloc(&h->ezx, h->field_bytes + 256) != hipSuccess || hipMalloc(&h->pml, fb) != hipSuccess)
+        if (hipMalloc(&h->ezxb[0], h->field_bytes + 256) != hipSuccess ||
+            hipMalloc(&h->ezxb[1], h->field_bytes + 256) != hipSuccess || hipMalloc(&h->pml, fb) != hipSuccess)
             return bail(fail(h, FDTD2D_E_NOMEM, "hipMalloc of the PML arrays failed"));
     }
     if (const char *e2 = std::getenv("FDTD2D_BAND_ROWS")) h->stream_band_rows = std::atoi(e2);
@@ -667,7 +702,7 @@ template <class T, bool PACK> int launch_halo(fdtd2d *h, int first, void *buf)
     const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 2048);
     if (h->boundary == FDTD2D_BOUNDARY_PML) {
         hipLaunchKernelGGL((fdtd::k_halo4<T, PACK>), dim3(blocks), dim3(256), 0, h->stream,
-                           (T *)h->ez[h->cur], (T *)h->ezx, (T *)h->hx(), (T *)h->hy(), (T *)buf, h->geom(),
+                           (T *)h->ez[h->cur], (T *)h->ezx(), (T *)h->hx(), (T *)h->hy(), (T *)buf, h->geom(),
                            first, h->halo);
         HIPCHK(h, hipGetLastError());
         return 0;
@@ -704,7 +739,7 @@ void fdtd2d_destroy(fdtd2d_t *h)
     if (!h) return;
     if (hipSetDevice(h->device) == hipSuccess) {
         if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
-        for (void *p : {h->ez[0], h->ez[1], h->hxb[0], h->hxb[1], h->hyb[0], h->hyb[1], h->ce, h->ch, h->ezx, h->pml})
+        for (void *p : {h->ez[0], h->ez[1], h->hxb[0], h->hxb[1], h->hyb[0], h->hyb[1], h->ce, h->ch, h->ezxb[0], h->ezxb[1], h->pml})
             if (p) (void)hipFree(p);
         if (h->scratch) (void)hipFree(h->scratch);
         if (h->t0) (void)hipEventDestroy(h->t0);
@@ -787,12 +822,16 @@ int fdtd2d_set_materials_uniform(fdtd2d_t *h, double eps, double mu)
     return 0;
 }
 
-int fdtd2d_set_pml(fdtd2d_t *h, const void *row_factors, const void *col_factors, int host_dtype)
+int fdtd2d_set_pml(fdtd2d_t *h, const void *row_factors, const void *col_factors, int host_dtype,
+                   int layer_cells)
 {
     if (!h) return FDTD2D_E_ARG;
     if (h->boundary != FDTD2D_BOUNDARY_PML) return fail(h, FDTD2D_E_STATE, "handle was not created with FDTD2D_BOUNDARY_PML");
     if (!row_factors || !col_factors) return fail(h, FDTD2D_E_ARG, "factor arrays must not be NULL");
     if (host_dtype != h->dtype) return fail(h, FDTD2D_E_ARG, "PML factors must have the engine's dtype");
+    if (layer_cells < 1 || 2 * layer_cells + 3 > std::min(h->rows, h->cols))
+        return fail(h, FDTD2D_E_ARG, "a %d-cell layer does not fit a %dx%d grid", layer_cells, h->rows, h->cols);
+    h->pml_L = layer_cells;
     int rc = use_device(h);
     if (rc) return rc;
     char *d = (char *)h->pml;
@@ -806,13 +845,13 @@ int fdtd2d_set_pml(fdtd2d_t *h, const void *row_factors, const void *col_factors
 int fdtd2d_transfer_ezx(fdtd2d_t *h, void *host, int host_dtype, int to_device)
 {
     if (!h || !host) return FDTD2D_E_ARG;
-    if (!h->ezx) return fail(h, FDTD2D_E_STATE, "no split field: handle was not created with FDTD2D_BOUNDARY_PML");
+    if (!h->ezxb[0]) return fail(h, FDTD2D_E_STATE, "no split field: handle was not created with FDTD2D_BOUNDARY_PML");
     if (host_dtype != FDTD2D_F32 && host_dtype != FDTD2D_F64) return fail(h, FDTD2D_E_ARG, "bad host_dtype");
     int rc = use_device(h);
     if (rc) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    return to_device ? copy_in(h, h->ezx, host, host_dtype, h->halo, h->nrows, h->cols)
-                     : copy_out(h, h->ezx, host, host_dtype, h->halo, h->nrows, h->cols);
+    return to_device ? copy_in(h, h->ezx(), host, host_dtype, h->halo, h->nrows, h->cols)
+                     : copy_out(h, h->ezx(), host, host_dtype, h->halo, h->nrows, h->cols);
 }
 
 double fdtd2d_courant(const fdtd2d_t *h)
@@ -937,7 +976,7 @@ int fdtd2d_pass_rows(fdtd2d_t *h, int nt, int row_lo, int row_hi, int src_row, i
     if (!pass_geometry(h, nt, &lo, &hi))
         return fail(h, FDTD2D_E_STATE, "a %d-step pass is not possible from the current state "
                     "(rows current: Ez [%d,%d), H [%d,%d))", nt, h->ev.lo, h->ev.hi, h->hv.lo, h->hv.hi);
-    const int zo = 5 + nt;
+    const int zo = h->boundary == FDTD2D_BOUNDARY_PML ? 0 : 5 + nt;   // no zones with the PML
     const int p_lo = h->top() ? 0 : lo, p_hi = h->bottom() ? h->rows : hi;   // rows a full pass writes
     if (row_lo < p_lo || row_hi > p_hi || row_lo >= row_hi)
         return fail(h, FDTD2D_E_ARG, "rows [%d,%d) are outside what this pass produces, [%d,%d)",

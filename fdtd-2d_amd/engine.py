@@ -133,7 +133,8 @@ class Engine:
         P = pml_profiles(self.rows, self.cols, courant00, L, m, R0, self.dtype)
         rowf = np.ascontiguousarray(np.concatenate([P["ahr"], P["bhr"], P["aer"], P["ber"]]))
         colf = np.ascontiguousarray(np.concatenate([P["ahc"], P["bhc"], P["aec"], P["bec"]]))
-        self._ck(self._lib.fdtd2d_set_pml(self._h, rowf.ctypes.data, colf.ctypes.data, _code(self.dtype)))
+        self._ck(self._lib.fdtd2d_set_pml(self._h, rowf.ctypes.data, colf.ctypes.data, _code(self.dtype),
+                                          int(L)))
         return self
 
     def upload_ezx(self, Ezx):

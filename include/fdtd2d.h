@@ -126,9 +126,11 @@ int fdtd2d_set_materials_uniform(fdtd2d_t *h, double eps, double mu);
  * time-domain PML): Berenger split-field layer.  row_factors = 4*rows values {ahr, bhr, aer,
  * ber}, col_factors = 4*cols values {ahc, bhc, aec, bec} (a = (1-s)/(1+s), b = 1/(1+s), 1
  * outside the layer; see oracle/pml_numpy.py / fdtd2d_amd.pml_profiles), in the engine's
- * dtype, for the GLOBAL grid (slabs index them by global row).  Ez is stored as total field
- * plus its x-part Ezx; fdtd2d_transfer_ezx moves the owned rows of Ezx (rows x cols). */
-int fdtd2d_set_pml(fdtd2d_t *h, const void *row_factors, const void *col_factors, int host_dtype);
+ * dtype, for the GLOBAL grid (slabs index them by global row); layer_cells = L, the depth of
+ * the layer: only cells within L of an edge use the split update, the rest the reference's
+ * (main.py:21-27).  Ez is stored as total field plus its x-part Ezx (zero outside the layer); fdtd2d_transfer_ezx moves the owned rows of Ezx (rows x cols). */
+int fdtd2d_set_pml(fdtd2d_t *h, const void *row_factors, const void *col_factors, int host_dtype,
+                   int layer_cells);
 int fdtd2d_transfer_ezx(fdtd2d_t *h, void *host, int host_dtype, int to_device);
 
 /* Courant number c*dt/dx from the smallest eps and mu given so far (fdtd.py:25-26). */

@@ -16,12 +16,16 @@ and d the depth into the layer in cells (E rows/columns at integer positions, Hx
 columns at half-integer positions), one step is, in this operation order,
     Hx[i,j]  = ahr[i]*Hx[i,j] - (bhr[i]*ch[i,j]) * (Ez[i+1,j] - Ez[i,j])          i <= R-2, j <= C-2
     Hy[i,j]  = ahc[j]*Hy[i,j] + (bhc[j]*ch[i,j]) * (Ez[i,j+1] - Ez[i,j])
+  inside the layer (row i or column j at depth > 0), 1 <= i <= R-2, 1 <= j <= C-2:
     ey       = Ez[i,j] - Ezx[i,j]
-    Ezx[i,j] = aec[j]*Ezx[i,j] + (bec[j]*ce[i,j]) * (Hy[i,j] - Hy[i,j-1])         1 <= i <= R-2
-    ey       = aer[i]*ey       - (ber[i]*ce[i,j]) * (Hx[i,j] - Hx[i-1,j])         1 <= j <= C-2
+    Ezx[i,j] = aec[j]*Ezx[i,j] + (bec[j]*ce[i,j]) * (Hy[i,j] - Hy[i,j-1])
+    ey       = aer[i]*ey       - (ber[i]*ce[i,j]) * (Hx[i,j] - Hx[i-1,j])
     Ez[i,j]  = Ezx[i,j] + ey
+  outside the layer the reference's own update (main.py:21-27), Ezx untouched (it stays 0):
+    Ez[i,j] += ((Hy[i,j] - Hy[i,j-1]) - (Hx[i,j] - Hx[i-1,j])) * ce[i,j]
 with ch = dt/(mu*dx), ce = dt/(eps*dx) as in the reference (main.py:27,70,74); the point source
-is added to Ez (total) afterwards, as fdtd.py:34 does.  Outside the layer a = b = 1.
+is added to Ez (total) afterwards, as fdtd.py:34 does.  Outside the layer a = b = 1, so the H
+updates reduce to the reference's exactly (x*1 is exact).
 """
 import numpy as np
 
@@ -33,9 +37,9 @@ def depth(n, L, half=False):
 
 
 def profiles(rows, cols, courant00, L=40, m=3, R0=1e-6, dtype=np.float64):
-    """The eight 1-D factor arrays, float64 math rounded once to dtype."""
+    """The eight 1-D factor arrays (float64 math rounded once to dtype) and the layer masks."""
     smax = (m + 1) * np.log(1.0 / R0) * courant00 / (4.0 * L)
-    out = {}
+    out = {"L": L}
     for name, n in (("r", rows), ("c", cols)):
         se = smax * (depth(n, L) / L) ** m
         sh = smax * (depth(n, L, half=True) / L) ** m
@@ -43,6 +47,7 @@ def profiles(rows, cols, courant00, L=40, m=3, R0=1e-6, dtype=np.float64):
         out["be" + name] = (1 / (1 + se)).astype(dtype)
         out["ah" + name] = ((1 - sh) / (1 + sh)).astype(dtype)
         out["bh" + name] = (1 / (1 + sh)).astype(dtype)
+        out["in_" + name] = depth(n, L) > 0
     return out
 
 
@@ -53,11 +58,15 @@ def step(Ez, Ezx, Hx, Hy, eps, mu, dt, dx, P):
     Hx[:-1, :] = P["ahr"][:-1, None] * Hx[:-1, :] - (P["bhr"][:-1, None] * ch) * (Ez[1:, :-1] - core)
     Hy[:, :-1] = P["ahc"][None, :-1] * Hy[:, :-1] + (P["bhc"][None, :-1] * ch) * (Ez[:-1, 1:] - core)
     ce = dt / (eps[1:-1, 1:-1] * dx)
+    dhy = Hy[1:, 1:-1] - Hy[1:, :-2]
+    dhx = Hx[1:-1, 1:] - Hx[:-2, 1:]
+    plain = Ez[1:-1, 1:-1] + (dhy - dhx) * ce
     ey = Ez[1:-1, 1:-1] - Ezx[1:-1, 1:-1]
-    Ezx[1:-1, 1:-1] = P["aec"][None, 1:-1] * Ezx[1:-1, 1:-1] + \
-        (P["bec"][None, 1:-1] * ce) * (Hy[1:, 1:-1] - Hy[1:, :-2])
-    ey = P["aer"][1:-1, None] * ey - (P["ber"][1:-1, None] * ce) * (Hx[1:-1, 1:] - Hx[:-2, 1:])
-    Ez[1:-1, 1:-1] = Ezx[1:-1, 1:-1] + ey
+    ex = P["aec"][None, 1:-1] * Ezx[1:-1, 1:-1] + (P["bec"][None, 1:-1] * ce) * dhy
+    ey = P["aer"][1:-1, None] * ey - (P["ber"][1:-1, None] * ce) * dhx
+    layer = P["in_r"][1:-1, None] | P["in_c"][None, 1:-1]
+    Ezx[1:-1, 1:-1] = np.where(layer, ex, Ezx[1:-1, 1:-1])
+    Ez[1:-1, 1:-1] = np.where(layer, ex + ey, plain)
     return Ez, Ezx, Hx, Hy
 
 

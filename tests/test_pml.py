@@ -13,7 +13,7 @@ def test_profiles_product_and_oracle_agree():
     for dtype in (np.float32, np.float64):
         a = fd.pml_profiles(130, 97, 0.15, 40, 3, 1e-6, dtype)
         b = pm.profiles(130, 97, 0.15, 40, 3, 1e-6, dtype)
-        assert set(a) == set(b)
+        assert set(a) | {"L", "in_r", "in_c"} == set(b)
         for k in a:
             assert np.array_equal(a[k], b[k]), k
         assert np.all(a["aer"][40:-40] == 1) and np.all(a["ber"][40:-40] == 1) and a["aer"][0] < 1
@@ -84,3 +84,42 @@ def test_device_pml_run_fdtd_absorbs():
     w = slice(60, 196)
     assert np.isfinite(Ep).all()
     assert float((Ep[w, w].astype(np.float64) ** 2).sum()) * 10 < float((Em[w, w].astype(np.float64) ** 2).sum())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("shape,L,arrays", [((96, 130), 20, True), ((200, 301), 40, False), ((150, 600), 30, True),
+                                             ((64, 64), 10, False)])
+def test_device_pml_passes_match_oracle(dtype, shape, L, arrays):
+    """8-step PML passes (k_pass_pml) + remainder steps, source inside the layer's cone."""
+    import fdtd2d_amd as fd
+    from oracle import fdtd_numpy as onp
+    from oracle import pml_numpy as pm
+    r, c = shape
+    rng = np.random.default_rng(r + c)
+    Ez = rng.standard_normal((r, c)).astype(dtype)
+    Hx = (rng.standard_normal((r, c - 1)) * 1e-3).astype(dtype)
+    Hy = (rng.standard_normal((r - 1, c)) * 1e-3).astype(dtype)
+    eps = (onp.EPS0 * (rng.uniform(1, 4, (r, c)) if arrays else np.full((r, c), 2.0))).astype(dtype)
+    mu = np.full((r, c), onp.MU0).astype(dtype)
+    S = 0.15
+    P = pm.profiles(r, c, S, L=L, dtype=dtype)
+    n = 27
+    amps = rng.standard_normal(n)
+    sr, sc = L // 2, c - L // 2 - 1
+    ref = [Ez.copy(), np.zeros_like(Ez), Hx.copy(), Hy.copy()]
+    pm.leapfrog(*ref, eps, mu, DT, DX, n, sr, sc, amps, P)
+    outs = []
+    for max_nt in (8, 0):
+        with fd.Engine(r, c, DT, DX, dtype=dtype, boundary="pml") as eng:
+            eng.set_materials(eps, mu).set_pml(L=L, courant00=S).set_option(max_pass_steps=max_nt)
+            eng.upload(Ez, Hx, Hy)
+            eng.run(n, sr, sc, amps)
+            got = eng.download()
+            gx = eng.download_ezx()
+            assert eng.info(16) == (3 if max_nt else 0)
+        outs.append((got[0], gx, got[1], got[2]))
+    for a, b, k in zip(outs[0], ref, ("Ez", "Ezx", "Hx", "Hy")):
+        assert np.array_equal(a, b), f"{k}: passes vs oracle {np.argwhere(a != b)[:4]}"
+    for a, b, k in zip(outs[1], ref, ("Ez", "Ezx", "Hx", "Hy")):
+        assert np.array_equal(a, b), f"{k}: step kernels vs oracle"

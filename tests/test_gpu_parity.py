@@ -382,3 +382,33 @@ def test_f64_passes_strip_seams_vs_right_band(fd, onp, cols):
         got = eng.download()
     for a, b, k in zip(got, ref, ("Ez", "Hx", "Hy")):
         assert np.array_equal(a, b), f"{k} cols={cols}: {np.argwhere(a != b)[:4]}"
+
+
+def test_randomised_geometries_float64(fd, onp):
+    """40 random configurations (grid shape, materials, band height, pass-length cap, step
+    count, source position anywhere incl. frame/zones/seams) in float64, where a wrong input
+    anywhere in a cell's dependency cone shows up as a bit difference."""
+    rng = np.random.default_rng(20261004)
+    for case in range(40):
+        r = int(rng.integers(44, 140))
+        c = int(rng.choice([rng.integers(16, 60), rng.integers(100, 130), rng.integers(220, 260),
+                            rng.integers(330, 360)]))
+        n = int(rng.integers(1, 30))
+        max_nt = int(rng.choice([8, 8, 4, 2, 1]))
+        band = int(rng.choice([0, 0, 1, 5, 16, 37]))
+        kind = rng.choice(["uniform", "eps", "eps+mu"])
+        Ez, Hx, Hy, eps, mu = _random_state(rng, r, c, np.float64, onp, vary_mu=(kind == "eps+mu"))
+        if kind == "uniform":
+            eps = np.full((r, c), 1.7 * onp.EPS0)
+        sr, sc = int(rng.integers(0, r)), int(rng.integers(0, c))
+        amps = rng.standard_normal(n)
+        ref = [a.copy() for a in (Ez, Hx, Hy)]
+        onp.leapfrog(*ref, eps, mu, DT, DX, n, sr, sc, amps=amps)
+        with fd.Engine(r, c, DT, DX, dtype=np.float64) as eng:
+            eng.set_materials(eps, mu).set_option(max_pass_steps=max_nt, band_rows=band)
+            eng.upload(Ez, Hx, Hy)
+            eng.run(n, sr, sc, amps)
+            got = eng.download()
+        for a, b, k in zip(got, ref, ("Ez", "Hx", "Hy")):
+            assert np.array_equal(a, b), (f"case {case}: {k} r={r} c={c} n={n} max_nt={max_nt} band={band} "
+                                          f"{kind} src=({sr},{sc}) first diff {np.argwhere(a != b)[:3]}")

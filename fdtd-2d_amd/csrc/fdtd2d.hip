@@ -49,6 +49,7 @@ struct fdtd2d {
     void *pml = nullptr;                  // PML only: 4 row + 4 column factor arrays, back to back
     bool have_pml = false;
     int pml_L = 0;
+    int pml_short_rows = 16;     // band height of the layer waves (FDTD2D_PML_SHORT overrides)
     int nfields() const { return boundary == FDTD2D_BOUNDARY_PML ? 4 : 3; }
     bool have_mat = false, ce_uniform = true, ch_uniform = true;
     double ce_u = 0, ch_u = 0;   // uniform coefficients, already rounded to T
@@ -78,6 +79,7 @@ struct fdtd2d {
     void *hx() const { return hxb[hcur]; }
     void *hy() const { return hyb[hcur]; }
     int stream_band_rows = 0;    // 0 = heuristic (FDTD2D_BAND_ROWS overrides)
+    int edge_band_div = 1;       // edge strips use band_rows / this (FDTD2D_EDGE_DIV; measured: no gain)
     int max_nt = 8;              // longest pass; FDTD2D_MAX_NT / set_option override (0: step kernels only)
 };
 
@@ -412,11 +414,13 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
     using D = fdtd::ZoneDims<NT>;
     const int region = std::max(0, p.band_hi - p.band_lo);
     p.nbands = (region + p.band_rows - 1) / p.band_rows;
+    p.band_rows_e = std::max(1, h->edge_band_div > 0 ? p.band_rows / h->edge_band_div : p.band_rows);
+    p.nbands_e = (region + p.band_rows_e - 1) / p.band_rows_e;
     p.zone_tiles = (h->cols + D::WZ - 1) / D::WZ;
-    // with a single strip the "last strip" slot of the launch order stays empty
-    const int strip_slots = p.nstrips == 1 ? 2 : p.nstrips;
-    const long long blocks = (long long)(p.zone_top + p.zone_bot) * p.zone_tiles +
-                             (long long)p.nbands * strip_slots;
+    // launch order: zone tiles, 2 edge-strip slots (the second stays empty with one strip),
+    // then strips 1 .. nstrips-2
+    const long long blocks = (long long)(p.zone_top + p.zone_bot) * p.zone_tiles + 2LL * p.nbands_e +
+                             (long long)p.nbands * std::max(0, p.nstrips - 2);
     if (blocks == 0) return 0;
     hipLaunchKernelGGL((fdtd::k_pass<T, NT, CE_ARR, CH_ARR>), dim3((unsigned)blocks), dim3(64), 0,
                        h->stream, p);
@@ -482,9 +486,20 @@ template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, 
         p.zone_tiles = 0;
         const int region = std::max(0, p.band_hi - p.band_lo);
         p.nbands = (region + p.band_rows - 1) / p.band_rows;
-        const int strip_slots = p.nstrips == 1 ? 2 : p.nstrips;
-        const long long blocks = (long long)p.nbands * strip_slots;
-        fdtd::PmlPass<T> q{pml_factors<T>(h), (const T *)h->ezxb[h->hcur], (T *)h->ezxb[h->hcur ^ 1]};
+        fdtd::PmlPass<T> q{pml_factors<T>(h), (const T *)h->ezxb[h->hcur], (T *)h->ezxb[h->hcur ^ 1],
+                           0, 0, 0, 0, 0, 0, 0};
+        // rows whose 8-step cone can touch the top / bottom layer: [0, L+1+16) and the mirror
+        const int reach = h->pml_L + 1 + 2 * nt;
+        q.short_rows = h->pml_short_rows;
+        auto up = [&](int x) { return (x + q.short_rows - 1) / q.short_rows * q.short_rows; };
+        q.a_hi = std::min(p.band_hi, std::max(p.band_lo, h->top() ? p.band_lo + up(reach - p.band_lo) : p.band_lo));
+        q.c_lo = std::max(q.a_hi, std::min(p.band_hi, h->bottom() ? p.band_hi - up(p.band_hi - (h->rows - reach)) : p.band_hi));
+        q.n1 = (region + q.short_rows - 1) / q.short_rows;
+        q.nA = (q.a_hi - p.band_lo + q.short_rows - 1) / q.short_rows;
+        q.nC = (p.band_hi - q.c_lo + q.short_rows - 1) / q.short_rows;
+        q.nB = (std::max(0, q.c_lo - q.a_hi) + p.band_rows - 1) / p.band_rows;
+        const int inner = std::max(0, p.nstrips - 2);
+        const long long blocks = 2LL * q.n1 + (long long)inner * (q.nA + q.nC + q.nB);
         if (blocks > 0) {
             if (h->ce_uniform)
                 hipLaunchKernelGGL((fdtd::k_pass_pml<T, false>), dim3((unsigned)blocks), dim3(64), 0, h->stream, p, q);
@@ -625,6 +640,8 @@ int create_impl(fdtd2d_t **out, int rows, int cols, int row0, int nrows, int hal
     }
     if (const char *e2 = std::getenv("FDTD2D_BAND_ROWS")) h->stream_band_rows = std::atoi(e2);
     if (const char *e2 = std::getenv("FDTD2D_MAX_NT")) h->max_nt = std::atoi(e2);
+    if (const char *e2 = std::getenv("FDTD2D_EDGE_DIV")) h->edge_band_div = std::max(1, std::atoi(e2));
+    if (const char *e2 = std::getenv("FDTD2D_PML_SHORT")) h->pml_short_rows = std::max(1, std::atoi(e2));
     rc = zero_fields(h);
     if (rc) return bail(rc);
     if (hipStreamSynchronize(h->stream) != hipSuccess)

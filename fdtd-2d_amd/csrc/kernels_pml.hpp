@@ -138,6 +138,12 @@ template <class T> struct PmlPass {
     PmlFactors<T> f;
     const T *ezx_in;
     T *ezx_out;
+    // Launch layout.  Waves that run pml_body are several times slower per row than plain
+    // waves, so they get short bands (short_rows) and come first in launch order:
+    //   class 1: strips 0 and last, rows [band_lo, band_hi) in short bands (n1 per strip)
+    //   class 2: strips 1..nstrips-2, rows [band_lo, a_hi) and [c_lo, band_hi) in short bands
+    //   class 3: strips 1..nstrips-2, rows [a_hi, c_lo) in normal bands (plain body)
+    int short_rows, a_hi, c_lo, n1, nA, nC, nB;
 };
 
 template <class T, bool CE_ARR> struct PmlSlot {
@@ -267,12 +273,33 @@ __global__ __launch_bounds__(64, 2) void k_pass_pml(const PassParams<T> p, const
     constexpr int NT = 8;
     constexpr int V = Vec<T>::N;
     constexpr int SW = 64 * V;
-    const int b = blockIdx.x;
-    const int sidx = b / p.nbands, band = b - sidx * p.nbands;
-    const int strip = sidx == 0 ? 0 : (sidx == 1 ? p.nstrips - 1 : sidx - 1);
-    if (sidx == 1 && p.nstrips == 1) return;
-    const int ra = p.band_lo + band * p.band_rows;
-    const int rb = min(ra + p.band_rows, p.band_hi);
+    int b = blockIdx.x;
+    int strip, ra, rb;
+    const int inner = max(0, p.nstrips - 2);
+    if (b < 2 * q.n1) {                               // class 1
+        const int sidx = b / q.n1, band = b - sidx * q.n1;
+        if (sidx == 1 && p.nstrips == 1) return;
+        strip = sidx == 0 ? 0 : p.nstrips - 1;
+        ra = p.band_lo + band * q.short_rows;
+        rb = min(ra + q.short_rows, p.band_hi);
+    } else if ((b -= 2 * q.n1) < inner * (q.nA + q.nC)) {   // class 2
+        const int per = q.nA + q.nC;
+        const int sidx = b / per, band = b - sidx * per;
+        strip = sidx + 1;
+        if (band < q.nA) {
+            ra = p.band_lo + band * q.short_rows;
+            rb = min(ra + q.short_rows, q.a_hi);
+        } else {
+            ra = q.c_lo + (band - q.nA) * q.short_rows;
+            rb = min(ra + q.short_rows, p.band_hi);
+        }
+    } else {                                          // class 3
+        b -= inner * (q.nA + q.nC);
+        const int sidx = b / q.nB, band = b - sidx * q.nB;
+        strip = sidx + 1;
+        ra = q.a_hi + band * p.band_rows;
+        rb = min(ra + p.band_rows, q.c_lo);
+    }
     if (ra >= rb) return;
     const int x0 = strip_x0<T, NT>(p, strip);
     const int L = q.f.L;

@@ -46,6 +46,8 @@ template <class T> struct PassParams {
     Geom g;
     int band_lo, band_hi;      // rows the streaming kernel produces
     int band_rows, nstrips, nbands;
+    int band_rows_e, nbands_e;   // shorter bands for the first/last strip (their GENERAL body is
+                               // slower per row; equal-height bands would make them the tail)
     int zone_top, zone_bot;    // 1 if this launch owns the grid's top / bottom zone
     int zone_tiles;            // column tiles per zone; the first (zone_top+zone_bot)*zone_tiles
                                // workgroups of the launch are zone tiles
@@ -384,12 +386,22 @@ __global__ __launch_bounds__(64, STREAM_WPE) void k_pass(const PassParams<T> p)
         return;
     }
     b -= nzone;
-    // strips in the order 0, last, 1, 2, ...; all bands of one strip are consecutive
-    const int sidx = b / p.nbands, band = b - sidx * p.nbands;
-    const int strip = sidx == 0 ? 0 : (sidx == 1 ? p.nstrips - 1 : sidx - 1);
-    if (sidx == 1 && p.nstrips == 1) return;
-    const int ra = p.band_lo + band * p.band_rows;
-    const int rb = min(ra + p.band_rows, p.band_hi);
+    // first the edge strips (0 and last) in their shorter bands, then strips 1, 2, ... in
+    // normal bands; all bands of one strip are consecutive
+    int strip, ra, rb;
+    if (b < 2 * p.nbands_e) {
+        const int sidx = b / p.nbands_e, band = b - sidx * p.nbands_e;
+        if (sidx == 1 && p.nstrips == 1) return;
+        strip = sidx == 0 ? 0 : p.nstrips - 1;
+        ra = p.band_lo + band * p.band_rows_e;
+        rb = min(ra + p.band_rows_e, p.band_hi);
+    } else {
+        b -= 2 * p.nbands_e;
+        const int sidx = b / p.nbands, band = b - sidx * p.nbands;
+        strip = sidx + 1;
+        ra = p.band_lo + band * p.band_rows;
+        rb = min(ra + p.band_rows, p.band_hi);
+    }
     if (ra >= rb) return;
     const int x0 = strip_x0<T, NT>(p, strip);
     // wave-uniform choice: all SW columns plain interior (5 <= j <= C-6) and the source cell

@@ -151,6 +151,13 @@ __device__ __forceinline__ void stream_body(const PassParams<T> &p, const int st
             slot[k].e.v[v] = slot[k].x.v[v] = slot[k].y.v[v] = slot[k].ce.v[v] = slot[k].ch.v[v] = T(0);
 
     auto load_row = [&](Slot<T, CE_ARR, CH_ARR> &r, int i) {
+#ifdef STREAM_EXP_NO_LOAD
+        if (ld_ok && i < tau1) {
+#pragma unroll
+            for (int v = 0; v < V; ++v) { r.e.v[v] = T(i + v); r.x.v[v] = T(0.5f * i); r.y.v[v] = T(v); }
+        }
+        return;
+#endif
         if (ld_ok && i < tau1) {
             const size_t o = at(g, i, 0) + col;
             r.e = ldv(p.ez_in + o);
@@ -185,6 +192,9 @@ __device__ __forceinline__ void stream_body(const PassParams<T> &p, const int st
             load_row(slot[(k + PF) % S], tau + PF);
 #pragma unroll
             for (int t = 1; t <= NT; ++t) {
+#ifdef STREAM_EXP_NO_COMPUTE
+                break;
+#endif
                 const int i = tau - t;                                   // row level t updates now
                 // level t is only needed on rows [ra-(NT-t)-1, rb+(NT-t)): skip the rest of the
                 // pipeline fill and drain (wave-uniform)

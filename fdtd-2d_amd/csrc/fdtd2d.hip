@@ -408,7 +408,7 @@ bool pass_geometry(const fdtd2d *h, int nt, int *band_lo, int *band_hi)
     return true;
 }
 
-template <class T, int NT, bool CE_ARR, bool CH_ARR>
+template <class T, int NT, bool CE_ARR, bool CH_ARR, int V = fdtd::Vec<T>::N>
 int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
 {
     using D = fdtd::ZoneDims<NT>;
@@ -422,7 +422,7 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
     const long long blocks = (long long)(p.zone_top + p.zone_bot) * p.zone_tiles + 2LL * p.nbands_e +
                              (long long)p.nbands * std::max(0, p.nstrips - 2);
     if (blocks == 0) return 0;
-    hipLaunchKernelGGL((fdtd::k_pass<T, NT, CE_ARR, CH_ARR>), dim3((unsigned)blocks), dim3(64), 0,
+    hipLaunchKernelGGL((fdtd::k_pass<T, NT, CE_ARR, CH_ARR, V>), dim3((unsigned)blocks), dim3(64), 0,
                        h->stream, p);
     HIPCHK(h, hipGetLastError());
     h->pass_launches++;
@@ -446,6 +446,8 @@ template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, 
                                    int src_col, const double *amps, bool ztop, bool zbot,
                                    bool commit, int full_lo, int full_hi)
 {
+    // (k_pass also instantiates with 2 columns per lane -- 86 VGPRs, 4-5 waves per SIMD -- but
+    // that measured 20 % slower than 4 columns: profiles/r01_kpass_ablation.txt)
     constexpr int V = fdtd::Vec<T>::N;
     const int OW = 64 * V - 2 * fdtd::stream_hc(nt);
     fdtd::PassParams<T> p;

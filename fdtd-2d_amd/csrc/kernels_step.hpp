@@ -22,6 +22,16 @@ template <class T> struct alignas(16) Vec {
     T v[N];
 };
 
+// N elements per lane, naturally aligned (N * sizeof(T) = 8 or 16 bytes -> dwordx2 / dwordx4)
+template <class T, int NN> struct alignas(NN * sizeof(T)) VecN {
+    static constexpr int N = NN;
+    T v[NN];
+};
+template <int NN, class T>
+__device__ __forceinline__ VecN<T, NN> ldn(const T *p) { return *reinterpret_cast<const VecN<T, NN> *>(p); }
+template <int NN, class T>
+__device__ __forceinline__ void stn(T *p, const VecN<T, NN> &x) { *reinterpret_cast<VecN<T, NN> *>(p) = x; }
+
 template <class T>
 __device__ __forceinline__ Vec<T> ldv(const T *p) { return *reinterpret_cast<const Vec<T> *>(p); }
 template <class T>

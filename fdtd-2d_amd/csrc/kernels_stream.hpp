@@ -83,17 +83,18 @@ __device__ __forceinline__ double from_prev(double x)
 // inside the right Mur band a cell depends on columns j-2..j of the previous level, so
 // invalid data entering from a strip's left edge would advance two columns per level
 // there; with the shift that edge is a full strip width away from the band.
-template <class T, int NT> __device__ __forceinline__ int strip_x0(const PassParams<T> &p, int strip)
+template <class T, int NT, int V = Vec<T>::N>
+__device__ __forceinline__ int strip_x0(const PassParams<T> &p, int strip)
 {
-    constexpr int SW = 64 * Vec<T>::N, HC = stream_hc(NT), OW = SW - 2 * HC;
+    constexpr int SW = 64 * V, HC = stream_hc(NT), OW = SW - 2 * HC;
     int x0 = strip * OW - HC;
     if (strip == p.nstrips - 1) x0 = min(x0, (p.g.C - SW + 3) & ~3);
     return x0;
 }
 
-template <class T, bool CE_ARR, bool CH_ARR> struct Slot {
-    Vec<T> e, x, y;
-    Vec<T> ce, ch;   // the row's coefficients ride along (only touched when arrays)
+template <class T, bool CE_ARR, bool CH_ARR, int V = Vec<T>::N> struct Slot {
+    VecN<T, V> e, x, y;
+    VecN<T, V> ce, ch;   // the row's coefficients ride along (only touched when arrays)
 };
 
 #ifndef STREAM_PF
@@ -110,18 +111,19 @@ template <class T, bool CE_ARR, bool CH_ARR> struct Slot {
 //   * the left/right 5-px Mur band of the row (main.py:34-41), under wave-uniform branches
 //     that only the first / last strip takes;
 //   * the point source (fdtd.py:34), under a wave-uniform row test.
-template <class T, int NT, bool CE_ARR, bool CH_ARR, bool GENERAL>
+template <class T, int NT, bool CE_ARR, bool CH_ARR, bool GENERAL, int V = Vec<T>::N>
 __device__ __forceinline__ void stream_body(const PassParams<T> &p, const int strip, const int ra,
                                             const int rb)
 {
-    constexpr int V = Vec<T>::N;
+    using VT = VecN<T, V>;
+    using SlotT = Slot<T, CE_ARR, CH_ARR, V>;
     constexpr int HC = stream_hc(NT);
     constexpr int SW = 64 * V, OW = SW - 2 * HC;
     constexpr int PF = STREAM_PF;          // rows in flight ahead of level 0
     constexpr int S = NT + PF + 2;         // ring of row slots; the tick loop is unrolled S times
     const Geom g = p.g;
     const int lane = threadIdx.x;
-    const int x0 = strip_x0<T, NT>(p, strip);
+    const int x0 = strip_x0<T, NT, V>(p, strip);
     const int j0 = x0 + V * lane;
     const bool ld_ok = j0 >= 0 && j0 < g.C;
     const bool st_ok = ld_ok && j0 >= strip * OW && j0 < (strip + 1) * OW;
@@ -129,7 +131,7 @@ __device__ __forceinline__ void stream_body(const PassParams<T> &p, const int st
     const int tau0 = ra - NT, tau1 = rb + NT;   // level-0 rows [tau0, tau1)
 
     // GENERAL: per-element masks (as 0/1 factors) and band membership, fixed for the strip
-    Vec<T> mh, me;
+    VT mh, me;
     bool in_l[V], in_r[V];
     const bool has_l = GENERAL && x0 < 5, has_r = GENERAL && x0 + SW > g.C - 5;
     if (GENERAL) {
@@ -143,14 +145,14 @@ __device__ __forceinline__ void stream_body(const PassParams<T> &p, const int st
         }
     }
 
-    Slot<T, CE_ARR, CH_ARR> slot[S];
+    SlotT slot[S];
 #pragma unroll
     for (int k = 0; k < S; ++k)
 #pragma unroll
         for (int v = 0; v < V; ++v)
             slot[k].e.v[v] = slot[k].x.v[v] = slot[k].y.v[v] = slot[k].ce.v[v] = slot[k].ch.v[v] = T(0);
 
-    auto load_row = [&](Slot<T, CE_ARR, CH_ARR> &r, int i) {
+    auto load_row = [&](SlotT &r, int i) {
 #ifdef STREAM_EXP_NO_LOAD
         if (ld_ok && i < tau1) {
 #pragma unroll
@@ -160,11 +162,11 @@ __device__ __forceinline__ void stream_body(const PassParams<T> &p, const int st
 #endif
         if (ld_ok && i < tau1) {
             const size_t o = at(g, i, 0) + col;
-            r.e = ldv(p.ez_in + o);
-            r.x = ldv(p.hx_in + o);
-            r.y = ldv(p.hy_in + o);
-            if (CE_ARR) r.ce = ldv(p.ce + o);
-            if (CH_ARR) r.ch = ldv(p.ch + o);
+            r.e = ldn<V>(p.ez_in + o);
+            r.x = ldn<V>(p.hx_in + o);
+            r.y = ldn<V>(p.hy_in + o);
+            if (CE_ARR) r.ce = ldn<V>(p.ce + o);
+            if (CH_ARR) r.ch = ldn<V>(p.ch + o);
             if (GENERAL) {   // fold the update masks into the row's coefficients once
 #pragma unroll
                 for (int v = 0; v < V; ++v) {
@@ -174,7 +176,7 @@ __device__ __forceinline__ void stream_body(const PassParams<T> &p, const int st
             }
         }
     };
-    Vec<T> ceu, chu;   // uniform coefficients, masked per element when GENERAL
+    VT ceu, chu;   // uniform coefficients, masked per element when GENERAL
 #pragma unroll
     for (int v = 0; v < V; ++v) {
         ceu.v[v] = GENERAL ? (me.v[v] != T(0) ? p.ce_u : T(0)) : p.ce_u;
@@ -199,12 +201,12 @@ __device__ __forceinline__ void stream_body(const PassParams<T> &p, const int st
                 // level t is only needed on rows [ra-(NT-t)-1, rb+(NT-t)): skip the rest of the
                 // pipeline fill and drain (wave-uniform)
                 if (i < ra - (NT - t) - 1 || i >= rb + (NT - t)) continue;
-                Slot<T, CE_ARR, CH_ARR> &c = slot[(k - t + 2 * S) % S];      // row i, level t-1 -> t
-                const Slot<T, CE_ARR, CH_ARR> &nx = slot[(k - t + 1 + 2 * S) % S];  // row i+1, level t-1
-                const Slot<T, CE_ARR, CH_ARR> &pv = slot[(k - t - 1 + 2 * S) % S];  // row i-1, level t
+                SlotT &c = slot[(k - t + 2 * S) % S];      // row i, level t-1 -> t
+                const SlotT &nx = slot[(k - t + 1 + 2 * S) % S];  // row i+1, level t-1
+                const SlotT &pv = slot[(k - t - 1 + 2 * S) % S];  // row i-1, level t
                 // H half-step of row i (main.py:66-76)
                 const T e_next_lane = from_next(c.e.v[0]);
-                Vec<T> po;      // Ez of row i before this step's E half-step (band rows only)
+                VT po;      // Ez of row i before this step's E half-step (band rows only)
                 if (GENERAL) po = c.e;
 #pragma unroll
                 for (int v = 0; v < V; ++v) {
@@ -225,7 +227,7 @@ __device__ __forceinline__ void stream_body(const PassParams<T> &p, const int st
                     // stage B: the 5-px Mur band of this row, B[j] = P[j+-1] + k (A[j+-1] - P[j])
                     if (has_l) {
                         const T a_next = from_next(c.e.v[0]);
-                        Vec<T> out;
+                        VT out;
 #pragma unroll
                         for (int v = 0; v < V; ++v) {
                             const T pr = (v + 1 < V) ? po.v[v + 1] : e_next_lane;
@@ -237,7 +239,7 @@ __device__ __forceinline__ void stream_body(const PassParams<T> &p, const int st
                     }
                     if (has_r) {
                         const T a_prev = from_prev(c.e.v[V - 1]), p_prev = from_prev(po.v[V - 1]);
-                        Vec<T> out;
+                        VT out;
 #pragma unroll
                         for (int v = 0; v < V; ++v) {
                             const T pl = (v > 0) ? po.v[v - 1] : p_prev;
@@ -256,11 +258,11 @@ __device__ __forceinline__ void stream_body(const PassParams<T> &p, const int st
             }
             const int io = tau - NT;
             if (io >= ra && st_ok) {
-                const Slot<T, CE_ARR, CH_ARR> &f = slot[(k - NT + 2 * S) % S];
+                const SlotT &f = slot[(k - NT + 2 * S) % S];
                 const size_t o = at(g, io, 0) + col;
-                stv(p.ez_out + o, f.e);
-                stv(p.hx_out + o, f.x);
-                stv(p.hy_out + o, f.y);
+                stn<V>(p.ez_out + o, f.e);
+                stn<V>(p.hx_out + o, f.x);
+                stn<V>(p.hy_out + o, f.y);
             }
         }
     }
@@ -383,10 +385,9 @@ __device__ __forceinline__ void zone_body(const PassParams<T> &p, const int tile
 #ifndef STREAM_WPE
 #define STREAM_WPE 2   // minimum waves per SIMD the register allocator must leave room for
 #endif
-template <class T, int NT, bool CE_ARR, bool CH_ARR>
+template <class T, int NT, bool CE_ARR, bool CH_ARR, int V = Vec<T>::N>
 __global__ __launch_bounds__(64, STREAM_WPE) void k_pass(const PassParams<T> p)
 {
-    constexpr int V = Vec<T>::N;
     constexpr int SW = 64 * V;
     int b = blockIdx.x;
     const int nzone = (p.zone_top + p.zone_bot) * p.zone_tiles;
@@ -413,16 +414,16 @@ __global__ __launch_bounds__(64, STREAM_WPE) void k_pass(const PassParams<T> p)
         rb = min(ra + p.band_rows, p.band_hi);
     }
     if (ra >= rb) return;
-    const int x0 = strip_x0<T, NT>(p, strip);
+    const int x0 = strip_x0<T, NT, V>(p, strip);
     // wave-uniform choice: all SW columns plain interior (5 <= j <= C-6) and the source cell
     // outside the rows/columns this wave ever touches -> mask-free body
     const bool edge = x0 < 5 || x0 + SW > p.g.C - 5;
     const bool src = p.src_row >= ra - 2 * NT && p.src_row < rb + NT && p.src_col >= x0 &&
                      p.src_col < x0 + SW;
     if (edge || src)
-        stream_body<T, NT, CE_ARR, CH_ARR, true>(p, strip, ra, rb);
+        stream_body<T, NT, CE_ARR, CH_ARR, true, V>(p, strip, ra, rb);
     else
-        stream_body<T, NT, CE_ARR, CH_ARR, false>(p, strip, ra, rb);
+        stream_body<T, NT, CE_ARR, CH_ARR, false, V>(p, strip, ra, rb);
 }
 
 }  // namespace fdtd

@@ -3,7 +3,7 @@
 sequencing + edge launches + pack/unpack, for a middle slab of 4096 x cols."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, torch.distributed as dist
 import fdtd2d_amd as fd
 from fdtd2d_amd.slab import SlabRunner

@@ -1,7 +1,7 @@
 import os, sys, time, subprocess
 # wall time per pass with experiment libs (results are wrong by construction; bench asserts finite field)
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import fdtd2d_amd as fd
 for g in (4096, 16384):
     with fd.Engine(g, g, dtype=np.float32) as e:

@@ -12,5 +12,5 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 /root/repo/bench.py --no-cpu-baseline "$@" > $out/stats.log 2>&1 || { echo stats failed; tail -5 $out/stats.log; exit 1; }
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -- python3 /root/repo/bench.py --no-cpu-baseline "$@" > $out/pmc_fetch.log 2>&1 || { echo pmc fetch failed; tail -5 $out/pmc_fetch.log; exit 1; }
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -- python3 /root/repo/bench.py --no-cpu-baseline "$@" > $out/pmc_write.log 2>&1 || { echo pmc write failed; tail -5 $out/pmc_write.log; exit 1; }
-python3 /root/repo/tools_prof_summary.py $out "$@" > $out/summary.txt
+python3 /root/repo/tools/tools_prof_summary.py $out "$@" > $out/summary.txt
 cat $out/summary.txt

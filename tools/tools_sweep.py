@@ -2,7 +2,7 @@
 """A/B sweep helper (GPU box): runs bench.py under env-selected library builds / knobs.
 usage: tools_sweep.py "<lib>:<max_nt>:<band_rows>:<grid>[:materials]" ...   (lib '' = default)"""
 import json, os, subprocess, sys
-root = os.path.dirname(os.path.abspath(__file__))
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for spec in sys.argv[1:]:
     parts = spec.split(":")
     lib, nt, br, grid = parts[:4]

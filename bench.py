@@ -20,7 +20,7 @@ Workloads (all synthetic: zero fields, ricker source at the grid centre, fp32):
 Timing: inputs resident in HBM; W untimed warm-up steps; barrier + device sync; K steps;
 device sync + barrier; max over ranks.  value = cells * K / time.
 
-roofline: the dominant kernel is k_pass (one launch = 8 time steps over the whole slab).
+roofline: the dominant kernel is k_bulk (one launch = 8 time steps over the whole slab).
 achieved = algorithmic bytes per launch / average launch duration, where algorithmic bytes
 = cells * steps-per-launch * (24 B + 4 B per non-uniform coefficient array) (SURVEY.md
 section 8 M2) and the duration comes from HIP events recorded on the engine's stream around
@@ -148,7 +148,7 @@ def measured_traffic(rows, cols, materials, steps_per_launch):
 def roofline_block(cells, steps, r):
     """Per-launch algorithmic rate of the dominant kernel."""
     if r["pass_launches"]:
-        launches, name = r["pass_launches"], "k_pass (temporally blocked, up to 8 steps per launch)"
+        launches, name = r["pass_launches"], "k_bulk (temporally blocked, up to 8 steps per launch)"
     else:
         launches, name = max(1, r["step_launches"] // 2), "k_update_h + k_update_e (one step)"
     ms = r["event_ms"] / launches
@@ -264,7 +264,7 @@ def main():
                        "per_gpu_slab": [slab, cols], "fields_finite": bool(ok)},
             "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS * world,
                          "unit": "GB/s", "frac": round(ach / (HBM_PEAK_GBS * world), 4),
-                         "traffic": None, "kernel": "k_pass, whole job (all ranks)",
+                         "traffic": None, "kernel": "k_bulk, whole job (all ranks)",
                          "bytes_per_cell_step": bpc},
             "weak_scaling": {"single_gpu_same_slab": round(single_v, 1),
                              "efficiency": round(value / (world * single_v), 4)},

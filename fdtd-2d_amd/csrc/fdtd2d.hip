@@ -65,6 +65,9 @@ struct fdtd2d {
 
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t t0 = nullptr, t1 = nullptr;
+    hipStream_t side_stream = nullptr;   // zone tiles run here, concurrently with the bulk
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    void *trash = nullptr;       // 4 KiB: destination of masked-off stores in k_bulk
     void *scratch = nullptr;     // device scratch for snapshots / reduction partials
     size_t scratch_bytes = 0;
     std::string err;
@@ -79,6 +82,7 @@ struct fdtd2d {
     void *hx() const { return hxb[hcur]; }
     void *hy() const { return hyb[hcur]; }
     int stream_band_rows = 0;    // 0 = heuristic (FDTD2D_BAND_ROWS overrides)
+    int zone_split = -1;         // -1: by launch size; 0/1: force fused / side-stream zones (FDTD2D_ZONE_SPLIT)
     int edge_band_div = 1;       // edge strips use band_rows / this (FDTD2D_EDGE_DIV; measured: no gain)
     int max_nt = 8;              // longest pass; FDTD2D_MAX_NT / set_option override (0: step kernels only)
 };
@@ -419,12 +423,28 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
     p.zone_tiles = (h->cols + D::WZ - 1) / D::WZ;
     // launch order: zone tiles, 2 edge-strip slots (the second stays empty with one strip),
     // then strips 1 .. nstrips-2
-    const long long blocks = (long long)(p.zone_top + p.zone_bot) * p.zone_tiles + 2LL * p.nbands_e +
-                             (long long)p.nbands * std::max(0, p.nstrips - 2);
-    if (blocks == 0) return 0;
-    hipLaunchKernelGGL((fdtd::k_pass<T, NT, CE_ARR, CH_ARR, V>), dim3((unsigned)blocks), dim3(64), 0,
-                       h->stream, p);
-    HIPCHK(h, hipGetLastError());
+    const long long bulk = 2LL * p.nbands_e + (long long)p.nbands * std::max(0, p.nstrips - 2);
+    const long long zones = (long long)(p.zone_top + p.zone_bot) * p.zone_tiles;
+    if (bulk + zones == 0) return 0;
+    // Small launches: zone tiles as k_zone on the side stream (ordered behind what is already
+    // on h->stream; everything later on h->stream waits for both).  Large launches: fused.
+    const bool split = zones > 0 && (h->zone_split < 0 ? bulk < 1600 : h->zone_split != 0);
+    p.fused_zones = zones > 0 && !split;
+    if (split) {
+        HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
+        HIPCHK(h, hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
+        hipLaunchKernelGGL((fdtd::k_zone<T, NT, CE_ARR, CH_ARR>), dim3((unsigned)zones),
+                           dim3(fdtd::PASS_THREADS), 0, h->side_stream, p);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipEventRecord(h->ev_join, h->side_stream));
+    }
+    const long long blocks = bulk + (p.fused_zones ? zones : 0);
+    if (blocks > 0) {
+        hipLaunchKernelGGL((fdtd::k_bulk<T, NT, CE_ARR, CH_ARR, V>), dim3((unsigned)blocks), dim3(64), 0,
+                           h->stream, p);
+        HIPCHK(h, hipGetLastError());
+    }
+    if (split) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
     h->pass_launches++;
     return 0;
 }
@@ -446,7 +466,7 @@ template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, 
                                    int src_col, const double *amps, bool ztop, bool zbot,
                                    bool commit, int full_lo, int full_hi)
 {
-    // (k_pass also instantiates with 2 columns per lane -- 86 VGPRs, 4-5 waves per SIMD -- but
+    // (k_bulk also instantiates with 2 columns per lane -- 86 VGPRs, 4-5 waves per SIMD -- but
     // that measured 20 % slower than 4 columns: profiles/r01_kpass_ablation.txt)
     constexpr int V = fdtd::Vec<T>::N;
     const int OW = 64 * V - 2 * fdtd::stream_hc(nt);
@@ -469,16 +489,17 @@ template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, 
     int br = h->stream_band_rows;
     if (br <= 0) {
         // Measured on MI355X (profiles/r01_band_sweep.txt): the pass is fastest with about
-        // 2300 waves in flight (256 CUs x 2 waves x 4 SIMDs, slightly oversubscribed) and
-        // bands of 32..128 rows; shorter bands pay too much pipeline fill, taller ones
-        // leave CUs idle at the tail.
+        // 2300 waves in flight (256 CUs x 2 waves x 4 SIMDs, slightly oversubscribed): 32 rows
+        // per band at 4096^2, 128 at 16384^2.  Small grids get bands down to 8 rows -- a lone
+        // wave issues one instruction per ~4 cycles, so its band height IS the pass latency.
         const int region = std::max(0, band_hi - band_lo);
         const int want = std::max(1, (2304 + p.nstrips - 1) / p.nstrips);
-        br = std::min(std::max(region / want, 32), 128);
+        br = std::min(std::max(region / want, 16), 128);
     }
     p.band_rows = std::max(br, 1);
     p.zone_top = ztop;
     p.zone_bot = zbot;
+    p.trash = (T *)h->trash;
     p.src_row = amps ? src_row : -1;
     p.src_col = amps ? src_col : -1;
     for (int s = 0; s < fdtd::STREAM_MAX_NT; ++s) p.amp[s] = (amps && s < nt) ? amps[s] : 0.0;
@@ -627,13 +648,18 @@ int create_impl(fdtd2d_t **out, int rows, int cols, int row0, int nrows, int hal
     if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess)
         return bail(fail(h, FDTD2D_E_NODEVICE, "hipStreamCreate failed"));
     h->stream = h->own_stream;
-    if (hipEventCreate(&h->t0) != hipSuccess || hipEventCreate(&h->t1) != hipSuccess)
-        return bail(fail(h, FDTD2D_E_NODEVICE, "hipEventCreate failed"));
+    if (hipEventCreate(&h->t0) != hipSuccess || hipEventCreate(&h->t1) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking) != hipSuccess)
+        return bail(fail(h, FDTD2D_E_NODEVICE, "hipEventCreate / hipStreamCreate failed"));
     for (void **p : {&h->ez[0], &h->ez[1], &h->hxb[0], &h->hxb[1], &h->hyb[0], &h->hyb[1]}) {
         // +256 B guard: the last lane of a row may look one vector past the row end
         if (hipMalloc(p, h->field_bytes + 256) != hipSuccess)
             return bail(fail(h, FDTD2D_E_NOMEM, "hipMalloc of %zu bytes failed", h->field_bytes));
     }
+    if (hipMalloc(&h->trash, 4096) != hipSuccess)
+        return bail(fail(h, FDTD2D_E_NOMEM, "hipMalloc of the scratch line failed"));
     if (boundary == FDTD2D_BOUNDARY_PML) {
         const size_t fb = (size_t)(h->rows + h->cols) * 4 * h->esz;
         if (hipMalloc(&h->ezxb[0], h->field_bytes + 256) != hipSuccess ||
@@ -643,6 +669,7 @@ int create_impl(fdtd2d_t **out, int rows, int cols, int row0, int nrows, int hal
     if (const char *e2 = std::getenv("FDTD2D_BAND_ROWS")) h->stream_band_rows = std::atoi(e2);
     if (const char *e2 = std::getenv("FDTD2D_MAX_NT")) h->max_nt = std::atoi(e2);
     if (const char *e2 = std::getenv("FDTD2D_EDGE_DIV")) h->edge_band_div = std::max(1, std::atoi(e2));
+    if (const char *e2 = std::getenv("FDTD2D_ZONE_SPLIT")) h->zone_split = std::atoi(e2);
     if (const char *e2 = std::getenv("FDTD2D_PML_SHORT")) h->pml_short_rows = std::max(1, std::atoi(e2));
     rc = zero_fields(h);
     if (rc) return bail(rc);
@@ -761,6 +788,10 @@ void fdtd2d_destroy(fdtd2d_t *h)
         for (void *p : {h->ez[0], h->ez[1], h->hxb[0], h->hxb[1], h->hyb[0], h->hyb[1], h->ce, h->ch, h->ezxb[0], h->ezxb[1], h->pml})
             if (p) (void)hipFree(p);
         if (h->scratch) (void)hipFree(h->scratch);
+        if (h->trash) (void)hipFree(h->trash);
+        if (h->side_stream) { (void)hipStreamSynchronize(h->side_stream); (void)hipStreamDestroy(h->side_stream); }
+        if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+        if (h->ev_join) (void)hipEventDestroy(h->ev_join);
         if (h->t0) (void)hipEventDestroy(h->t0);
         if (h->t1) (void)hipEventDestroy(h->t1);
         if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -1087,6 +1118,10 @@ int fdtd2d_set_option(fdtd2d_t *h, int option, long long value)
     case FDTD2D_OPT_BAND_ROWS:
         if (value < 0) return fail(h, FDTD2D_E_ARG, "band rows must be >= 0");
         h->stream_band_rows = (int)value;
+        return 0;
+    case FDTD2D_OPT_ZONE_SPLIT:
+        if (value < -1 || value > 1) return fail(h, FDTD2D_E_ARG, "zone split must be -1, 0 or 1");
+        h->zone_split = (int)value;
         return 0;
     default: return fail(h, FDTD2D_E_ARG, "unknown option %d", option);
     }

@@ -127,13 +127,13 @@ __global__ __launch_bounds__(256) void k_update_e_pml(const T *__restrict__ ez_o
 }
 
 // ---- temporally blocked pass with the PML (8 steps per launch) ----------------------------------
-// Same streaming scheme as k_pass (kernels_stream.hpp): one wave per (band, strip), row-slot
+// Same streaming scheme as k_bulk (kernels_stream.hpp): one wave per (band, strip), row-slot
 // ring in registers, DPP lane shifts.  There are no top/bottom zones in PML mode (no row
 // coupling beyond the stencil), so the bands cover all rows and the body guards the grid's
 // first/last row itself.  Waves whose dependency cone touches the layer run pml_body, which
 // carries the split field Ezx in the slot and selects per cell between the split update
 // (inside the layer) and the reference's update (outside); all other waves run the plain
-// mask-free body of k_pass and never touch Ezx.
+// mask-free body of k_bulk and never touch Ezx.
 template <class T> struct PmlPass {
     PmlFactors<T> f;
     const T *ezx_in;

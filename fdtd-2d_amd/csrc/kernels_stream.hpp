@@ -33,6 +33,7 @@
 
 namespace fdtd {
 
+constexpr int PASS_THREADS = 256;    // threads per zone tile (4 waves share the tile through LDS)
 constexpr int STREAM_MAX_NT = 12;   // longest pass (register budget: (NT + 4) slots x 12 VGPRs)
 // halo columns per strip side: >= NT (validity shrinks one column per level from a strip
 // edge) and a multiple of 4 so that every lane's 16-byte access stays aligned
@@ -49,8 +50,10 @@ template <class T> struct PassParams {
     int band_rows_e, nbands_e;   // shorter bands for the first/last strip (their GENERAL body is
                                // slower per row; equal-height bands would make them the tail)
     int zone_top, zone_bot;    // 1 if this launch owns the grid's top / bottom zone
-    int zone_tiles;            // column tiles per zone; the first (zone_top+zone_bot)*zone_tiles
-                               // workgroups of the launch are zone tiles
+    int zone_tiles;            // column tiles per zone
+    int fused_zones;           // 1: the zone tiles are the first workgroups of the k_bulk launch
+                               // (one wave each); 0: k_zone runs them on a side stream
+    T *trash;                  // >= 3 x 1 KiB of device scratch: where masked-off stores land
     int src_row, src_col;      // -1: no source
     double amp[STREAM_MAX_NT]; // amplitude added after step s = 1..NT of this pass
 };
@@ -60,8 +63,13 @@ template <class T> struct PassParams {
 // (lane 63 / lane 0 get 0: those are strip-edge lanes whose results are never used)
 __device__ __forceinline__ int dpp_next(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x130, 0xF, 0xF, true); }
 __device__ __forceinline__ int dpp_prev(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x138, 0xF, 0xF, true); }
+#ifdef STREAM_EXP_NO_DPP
+__device__ __forceinline__ float from_next(float x) { return x * 0.5f; }
+__device__ __forceinline__ float from_prev(float x) { return x * 0.25f; }
+#else
 __device__ __forceinline__ float from_next(float x) { return __builtin_bit_cast(float, dpp_next(__builtin_bit_cast(int, x))); }
 __device__ __forceinline__ float from_prev(float x) { return __builtin_bit_cast(float, dpp_prev(__builtin_bit_cast(int, x))); }
+#endif
 __device__ __forceinline__ double from_next(double x)
 {
     const long long b = __builtin_bit_cast(long long, x);
@@ -119,7 +127,9 @@ __device__ __forceinline__ void stream_body(const PassParams<T> &p, const int st
     using SlotT = Slot<T, CE_ARR, CH_ARR, V>;
     constexpr int HC = stream_hc(NT);
     constexpr int SW = 64 * V, OW = SW - 2 * HC;
-    constexpr int PF = STREAM_PF;          // rows in flight ahead of level 0
+    // rows in flight ahead of level 0 (the GENERAL body gives one up to stay within the
+    // 168 VGPRs that allow 3 waves per SIMD for the whole kernel)
+    constexpr int PF = GENERAL ? 1 : STREAM_PF;
     constexpr int S = NT + PF + 2;         // ring of row slots; the tick loop is unrolled S times
     const Geom g = p.g;
     const int lane = threadIdx.x;
@@ -152,27 +162,33 @@ __device__ __forceinline__ void stream_body(const PassParams<T> &p, const int st
         for (int v = 0; v < V; ++v)
             slot[k].e.v[v] = slot[k].x.v[v] = slot[k].y.v[v] = slot[k].ce.v[v] = slot[k].ch.v[v] = T(0);
 
+    // Memory operations in the tick loop are UNCONDITIONAL (rows clamped into the band's
+    // range, masked-off lanes redirected): with loads or stores under a branch the compiler
+    // can no longer count outstanding operations exactly and falls back to s_waitcnt
+    // vmcnt(0) in front of every level -- which serialises the prefetch (measured: 58 % of
+    // wave time in s_waitcnt, profiles/r01_kpass_ablation.txt).
     auto load_row = [&](SlotT &r, int i) {
 #ifdef STREAM_EXP_NO_LOAD
-        if (ld_ok && i < tau1) {
 #pragma unroll
-            for (int v = 0; v < V; ++v) { r.e.v[v] = T(i + v); r.x.v[v] = T(0.5f * i); r.y.v[v] = T(v); }
-        }
+        for (int v = 0; v < V; ++v) { r.e.v[v] = T(i + v); r.x.v[v] = T(0.5f * i); r.y.v[v] = T(v); }
         return;
 #endif
-        if (ld_ok && i < tau1) {
-            const size_t o = at(g, i, 0) + col;
-            r.e = ldn<V>(p.ez_in + o);
-            r.x = ldn<V>(p.hx_in + o);
-            r.y = ldn<V>(p.hy_in + o);
-            if (CE_ARR) r.ce = ldn<V>(p.ce + o);
-            if (CH_ARR) r.ch = ldn<V>(p.ch + o);
-            if (GENERAL) {   // fold the update masks into the row's coefficients once
+        const int ic = min(i, tau1 - 1);             // rows past the band are never used
+        const size_t o = at(g, ic, 0) + col;         // lanes outside the grid read column 0
+        r.e = ldn<V>(p.ez_in + o);
+        r.x = ldn<V>(p.hx_in + o);
+        r.y = ldn<V>(p.hy_in + o);
+        if (CE_ARR) r.ce = ldn<V>(p.ce + o);
+        if (CH_ARR) r.ch = ldn<V>(p.ch + o);
+        if (GENERAL) {
 #pragma unroll
-                for (int v = 0; v < V; ++v) {
-                    if (CE_ARR) r.ce.v[v] = me.v[v] != T(0) ? r.ce.v[v] : T(0);
-                    if (CH_ARR) r.ch.v[v] = mh.v[v] != T(0) ? r.ch.v[v] : T(0);
-                }
+            for (int v = 0; v < V; ++v) {
+                // lanes outside the grid hold zeros; update masks fold into the coefficients
+                r.e.v[v] = ld_ok ? r.e.v[v] : T(0);
+                r.x.v[v] = ld_ok ? r.x.v[v] : T(0);
+                r.y.v[v] = ld_ok ? r.y.v[v] : T(0);
+                if (CE_ARR) r.ce.v[v] = (ld_ok && me.v[v] != T(0)) ? r.ce.v[v] : T(0);
+                if (CH_ARR) r.ch.v[v] = (ld_ok && mh.v[v] != T(0)) ? r.ch.v[v] : T(0);
             }
         }
     };
@@ -200,7 +216,9 @@ __device__ __forceinline__ void stream_body(const PassParams<T> &p, const int st
                 const int i = tau - t;                                   // row level t updates now
                 // level t is only needed on rows [ra-(NT-t)-1, rb+(NT-t)): skip the rest of the
                 // pipeline fill and drain (wave-uniform)
+#ifndef STREAM_EXP_NO_SKIP
                 if (i < ra - (NT - t) - 1 || i >= rb + (NT - t)) continue;
+#endif
                 SlotT &c = slot[(k - t + 2 * S) % S];      // row i, level t-1 -> t
                 const SlotT &nx = slot[(k - t + 1 + 2 * S) % S];  // row i+1, level t-1
                 const SlotT &pv = slot[(k - t - 1 + 2 * S) % S];  // row i-1, level t
@@ -256,13 +274,15 @@ __device__ __forceinline__ void stream_body(const PassParams<T> &p, const int st
                     }
                 }
             }
-            const int io = tau - NT;
-            if (io >= ra && st_ok) {
+            {
+                const int io = tau - NT;
                 const SlotT &f = slot[(k - NT + 2 * S) % S];
-                const size_t o = at(g, io, 0) + col;
-                stn<V>(p.ez_out + o, f.e);
-                stn<V>(p.hx_out + o, f.x);
-                stn<V>(p.hy_out + o, f.y);
+                const bool keep = st_ok && io >= ra;           // else: pipeline fill / overlap lanes
+                const size_t o = at(g, max(io, ra), 0) + col;
+                const size_t d = (size_t)lane * V;
+                stn<V>(keep ? p.ez_out + o : p.trash + d, f.e);
+                stn<V>(keep ? p.hx_out + o : p.trash + d + 64 * V, f.x);
+                stn<V>(keep ? p.hy_out + o : p.trash + d + 128 * V, f.y);
             }
         }
     }
@@ -292,16 +312,18 @@ template <class T, bool CE_ARR> struct TileAcc {
     __device__ __forceinline__ T ce(int i, int j) const { return CE_ARR ? cearr[at(g, i, j)] : ce_u; }
 };
 
-template <class T, int NT, bool CE_ARR, bool CH_ARR>
+template <class T, int NT, bool CE_ARR, bool CH_ARR, int THREADS>
 __device__ __forceinline__ void zone_body(const PassParams<T> &p, const int tile, const bool bottom)
 {
     using D = ZoneDims<NT>;
-    constexpr int NTH = 64;
+    static_assert(D::WL == 32, "lane -> column mapping below assumes 32-column tiles");
     __shared__ T sE[2][D::ZR * D::WLP];
     __shared__ T sX[D::ZR * D::WLP];
     __shared__ T sY[D::ZR * D::WLP];
     const Geom g = p.g;
-    const int tid = threadIdx.x;
+    // thread -> (row group, column): THREADS/32 tile rows per sweep, no integer division
+    constexpr int RG = THREADS / 32;
+    const int lj = threadIdx.x & 31, lr = threadIdx.x >> 5;
     // rows held [z0, z0+ZR), rows written [o0, o0+ZO)
     const int z0 = bottom ? g.R - D::ZR : 0;
     const int o0 = bottom ? g.R - D::ZO : 0;
@@ -311,15 +333,22 @@ __device__ __forceinline__ void zone_body(const PassParams<T> &p, const int tile
     const int w0 = min(tile * D::WZ, max(0, g.C - D::WZ)), w1 = min(w0 + D::WZ, g.C);
     const int c0 = max(0, w0 - D::M), c1 = min(g.C, w0 + D::WZ + D::M);
     const int wl = c1 - c0;
-    const int ncell = D::ZR * wl;
+    const int j = c0 + lj;
+    const bool col_ok = lj < wl;
+    // does this tile hold columns of the left/right Mur band (or the edge columns)?  wave-uniform
+    const bool lr_band = c0 < 5 || c1 > g.C - 5;
+    const bool col_band = j < 5 || j >= g.C - 5;
 
-    for (int n = tid; n < ncell; n += NTH) {
-        const int li = n / wl, lj = n - li * wl;
-        const size_t o = at(g, z0 + li, c0 + lj);
-        const int s = li * D::WLP + lj;
-        sE[0][s] = p.ez_in[o];
-        sX[s] = p.hx_in[o];
-        sY[s] = p.hy_in[o];
+#pragma unroll
+    for (int it = 0; it < (D::ZR + RG - 1) / RG; ++it) {     // unrolled: all loads in flight at once
+        const int li = lr + it * RG;
+        if (col_ok && li < D::ZR) {
+            const size_t o = at(g, z0 + li, j);
+            const int s = li * D::WLP + lj;
+            sE[0][s] = p.ez_in[o];
+            sX[s] = p.hx_in[o];
+            sY[s] = p.hy_in[o];
+        }
     }
     __syncthreads();
 
@@ -329,10 +358,9 @@ __device__ __forceinline__ void zone_body(const PassParams<T> &p, const int tile
         const T *Eo = sE[cur];
         T *En = sE[cur ^ 1];
         // H half-step (main.py:66-76) on every cell whose i+1 / j+1 neighbours are in the tile
-        for (int n = tid; n < ncell; n += NTH) {
-            const int li = n / wl, lj = n - li * wl;
-            const int i = z0 + li, j = c0 + lj;
-            if (i <= g.R - 2 && j <= g.C - 2 && li + 1 < D::ZR && lj + 1 < wl) {
+        for (int li = lr; li < D::ZR; li += RG) {
+            const int i = z0 + li;
+            if (col_ok && i <= g.R - 2 && j <= g.C - 2 && li + 1 < D::ZR && lj + 1 < wl) {
                 const int s = li * D::WLP + lj;
                 const T ch = CH_ARR ? p.ch[at(g, i, j)] : p.ch_u;
                 const T e = Eo[s];
@@ -341,64 +369,78 @@ __device__ __forceinline__ void zone_body(const PassParams<T> &p, const int tile
             }
         }
         __syncthreads();
-        // E half-step: stages A-D as one pure function of (Eo, new H) per cell
+        // E half-step: stages A-D as one pure function of (Eo, new H) per cell; plain interior
+        // cells (the vast majority) take the direct formula
         MurRules<T, TileAcc<T, CE_ARR>> rules{{Eo, sX, sY, p.ce, p.ce_u, g, g.R, g.C, z0, c0, D::WLP}, p.k};
-        for (int n = tid; n < ncell; n += NTH) {
-            const int li = n / wl, lj = n - li * wl;
-            const int i = z0 + li, j = c0 + lj;
+        for (int li = lr; li < D::ZR; li += RG) {
+            const int i = z0 + li;
             const int s = li * D::WLP + lj;
-            // needs the row above and the column to the left inside the tile unless the
-            // cell sits on the physical edge (where the rules never look outward)
-            const bool ok = (li >= 1 || i == 0) && (lj >= 1 || j == 0);
-            T val = Eo[s];
-            if (ok) {
-                if (i >= 5 && i < g.R - 5 && j >= 5 && j < g.C - 5) {   // plain interior cell
-                    const T ce = CE_ARR ? p.ce[at(g, i, j)] : p.ce_u;
-                    val = val + ((sY[s] - sY[s - 1]) - (sX[s] - sX[s - D::WLP])) * ce;
-                } else {
-                    val = rules.d(i, j);
+            if (col_ok) {
+                // needs the row above and the column to the left inside the tile unless the
+                // cell sits on the physical edge (where the rules never look outward)
+                const bool ok = (li >= 1 || i == 0) && (lj >= 1 || j == 0);
+                T val = Eo[s];
+                if (ok) {
+                    const bool row_band = i < 5 || i >= g.R - 5;
+                    if (row_band || (lr_band && col_band)) {
+                        val = rules.d(i, j);
+                    } else {
+                        const T ce = CE_ARR ? p.ce[at(g, i, j)] : p.ce_u;
+                        val = val + ((sY[s] - sY[s - 1]) - (sX[s] - sX[s - D::WLP])) * ce;
+                    }
                 }
+                if (i == p.src_row && j == p.src_col) val = (T)((double)val + p.amp[step - 1]);
+                En[s] = val;
             }
-            if (i == p.src_row && j == p.src_col) val = (T)((double)val + p.amp[step - 1]);
-            En[s] = val;
         }
         __syncthreads();
         cur ^= 1;
     }
 
     const T *Ef = sE[cur];
-    const int ow = w1 - w0;
-    for (int n = tid; n < D::ZO * ow; n += NTH) {
-        const int r = n / ow, q = n - r * ow;
-        const int i = o0 + r, j = w0 + q;
-        const int s = (i - z0) * D::WLP + (j - c0);
-        const size_t o = at(g, i, j);
-        p.ez_out[o] = Ef[s];
-        p.hx_out[o] = sX[s];
-        p.hy_out[o] = sY[s];
+    for (int r = lr; r < D::ZO; r += RG) {
+        const int i = o0 + r;
+        if (col_ok && j >= w0 && j < w1) {
+            const int s = (i - z0) * D::WLP + lj;
+            const size_t o = at(g, i, j);
+            p.ez_out[o] = Ef[s];
+            p.hx_out[o] = sX[s];
+            p.hy_out[o] = sY[s];
+        }
     }
 }
 
-// ---- one launch per pass -------------------------------------------------------------------------
-// Workgroups (one wave each), in launch order: zone tiles, then the strips that need the
-// GENERAL body (first and last strip: they run longer, so they start first), then the rest.
+// ---- launches ---------------------------------------------------------------------------------
+// k_bulk: one wave per workgroup, one (band, strip) task each; launch order: the edge strips
+// (0 and last: they run the slower GENERAL body), then strips 1, 2, ...; no barriers.
+// Zone tiles either ride in the same launch (first workgroups, one wave per tile) or run as
+// k_zone (256 threads per tile) on a side stream, joined back by events.  A tile is a long
+// dependent chain of LDS phases (~80 us with one wave, ~25 us with four): on small grids it
+// would set the pass latency, so they take k_zone; on large grids the bulk dominates and the
+// cross-stream join costs more than it saves, so they take the fused form
+// (profiles/r01_kpass_ablation.txt).
+// Minimum waves per SIMD the register allocator must leave room for: 3 (<= 168 VGPRs) for
+// uniform materials -- the slot ring alone is 144 -- and 2 when coefficient rows ride along.
 #ifndef STREAM_WPE
-#define STREAM_WPE 2   // minimum waves per SIMD the register allocator must leave room for
+#define STREAM_WPE(arr) 2
 #endif
 template <class T, int NT, bool CE_ARR, bool CH_ARR, int V = Vec<T>::N>
-__global__ __launch_bounds__(64, STREAM_WPE) void k_pass(const PassParams<T> p)
+__global__ __launch_bounds__(64, STREAM_WPE(CE_ARR || CH_ARR || NT > 8 || sizeof(T) > 4))
+void k_bulk(const PassParams<T> p)
 {
     constexpr int SW = 64 * V;
     int b = blockIdx.x;
-    const int nzone = (p.zone_top + p.zone_bot) * p.zone_tiles;
-    if (b < nzone) {
-        const int z = b / p.zone_tiles;
-        zone_body<T, NT, CE_ARR, CH_ARR>(p, b - z * p.zone_tiles, p.zone_top ? z == 1 : true);
-        return;
+    if (p.fused_zones) {     // zone tiles as the first workgroups of this launch (one wave each)
+        const int nzone = (p.zone_top + p.zone_bot) * p.zone_tiles;
+        if (b < nzone) {
+            const int z = b / p.zone_tiles;
+            zone_body<T, NT, CE_ARR, CH_ARR, 64>(p, b - z * p.zone_tiles, p.zone_top ? z == 1 : true);
+            return;
+        }
+        b -= nzone;
     }
-    b -= nzone;
-    // first the edge strips (0 and last) in their shorter bands, then strips 1, 2, ... in
-    // normal bands; all bands of one strip are consecutive
+    // first the edge strips (0 and last) in their (optionally shorter) bands, then strips
+    // 1, 2, ... in normal bands; all bands of one strip are consecutive
     int strip, ra, rb;
     if (b < 2 * p.nbands_e) {
         const int sidx = b / p.nbands_e, band = b - sidx * p.nbands_e;
@@ -424,6 +466,13 @@ __global__ __launch_bounds__(64, STREAM_WPE) void k_pass(const PassParams<T> p)
         stream_body<T, NT, CE_ARR, CH_ARR, true, V>(p, strip, ra, rb);
     else
         stream_body<T, NT, CE_ARR, CH_ARR, false, V>(p, strip, ra, rb);
+}
+
+template <class T, int NT, bool CE_ARR, bool CH_ARR>
+__global__ __launch_bounds__(PASS_THREADS) void k_zone(const PassParams<T> p)
+{
+    const int z = blockIdx.x / p.zone_tiles;
+    zone_body<T, NT, CE_ARR, CH_ARR, PASS_THREADS>(p, blockIdx.x - z * p.zone_tiles, p.zone_top ? z == 1 : true);
 }
 
 }  // namespace fdtd

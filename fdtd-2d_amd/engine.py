@@ -255,13 +255,15 @@ class Engine:
                                                int(src_col), float(fc), int(step0)))
         return self
 
-    def set_option(self, max_pass_steps=None, band_rows=None):
+    def set_option(self, max_pass_steps=None, band_rows=None, zone_split=None):
         """Speed knobs of run(): longest temporally blocked pass (0 = single-step kernels
         only) and rows per streaming band.  Results do not depend on them."""
         if max_pass_steps is not None:
             self._ck(self._lib.fdtd2d_set_option(self._h, _abi.OPT_MAX_PASS_STEPS, int(max_pass_steps)))
         if band_rows is not None:
             self._ck(self._lib.fdtd2d_set_option(self._h, _abi.OPT_BAND_ROWS, int(band_rows)))
+        if zone_split is not None:
+            self._ck(self._lib.fdtd2d_set_option(self._h, _abi.OPT_ZONE_SPLIT, int(zone_split)))
         return self
 
     def sync(self):

@@ -10,7 +10,7 @@ import csv, glob, collections
 acc = collections.defaultdict(list)
 for f in glob.glob("$out/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "k_pass" in r["Kernel_Name"]:
+        if "k_bulk" in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, v in sorted(acc.items()):
     vv = v[len(v)//2:]

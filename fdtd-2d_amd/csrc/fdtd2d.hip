@@ -488,12 +488,12 @@ template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, 
     p.nstrips = (h->cols + OW - 1) / OW;
     int br = h->stream_band_rows;
     if (br <= 0) {
-        // Measured on MI355X (profiles/r01_band_sweep.txt): the pass is fastest with about
-        // 2300 waves in flight (256 CUs x 2 waves x 4 SIMDs, slightly oversubscribed): 32 rows
-        // per band at 4096^2, 128 at 16384^2.  Small grids get bands down to 8 rows -- a lone
-        // wave issues one instruction per ~4 cycles, so its band height IS the pass latency.
+        // Measured on MI355X (interleaved A/B, profiles/r01_band_sweep.txt): the pass is fastest
+        // with about one wave per wave slot (1024 SIMDs x 3 waves) and bands of 16..128 rows:
+        // 16 rows at 2048^2, 24 at 4096^2, 64-96 at 8192^2, 96-192 at 16384^2.  Shorter bands pay
+        // too much pipeline fill, taller ones leave SIMDs without a second wave to switch to.
         const int region = std::max(0, band_hi - band_lo);
-        const int want = std::max(1, (2304 + p.nstrips - 1) / p.nstrips);
+        const int want = std::max(1, (3072 + p.nstrips - 1) / p.nstrips);
         br = std::min(std::max(region / want, 16), 128);
     }
     p.band_rows = std::max(br, 1);

@@ -784,6 +784,7 @@ void fdtd2d_destroy(fdtd2d_t *h)
 {
     if (!h) return;
     if (hipSetDevice(h->device) == hipSuccess) {
+        if (h->stream && h->stream != h->own_stream) (void)hipStreamSynchronize(h->stream);
         if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
         for (void *p : {h->ez[0], h->ez[1], h->hxb[0], h->hxb[1], h->hyb[0], h->hyb[1], h->ce, h->ch, h->ezxb[0], h->ezxb[1], h->pml})
             if (p) (void)hipFree(p);
@@ -924,8 +925,14 @@ int fdtd2d_upload(fdtd2d_t *h, const void *Ez, const void *Hx, const void *Hy, i
     if (Hx && (rc = copy_in(h, h->hx(), Hx, host_dtype, s, h->nrows, h->cols - 1))) return rc;
     const int hy_rows = std::min(h->row0 + h->nrows, h->rows - 1) - h->row0;
     if (Hy && (rc = copy_in(h, h->hy(), Hy, host_dtype, s, hy_rows, h->cols))) return rc;
-    // owned rows are current; halo rows are not until the next exchange
-    h->ev = h->hv = Range{h->row0, h->row0 + h->nrows};
+    // uploaded fields are current on the owned rows; halo rows are not until the next exchange
+    const Range owned{h->row0, h->row0 + h->nrows};
+    if (Ez) h->ev = owned;
+    if (Hx || Hy) h->hv = owned;
+    if (h->pend_nt) {          // an uncommitted partial pass refers to the old fields: drop it
+        h->pend_nt = 0;
+        h->pend_done.clear();
+    }
     return 0;
 }
 

@@ -62,6 +62,7 @@ SIGNATURES = {
     "fdtd2d_reduce": (_i, [_vp, _i, C.POINTER(_d), C.POINTER(_d)]),
     "fdtd2d_timer_start": (_i, [_vp]),
     "fdtd2d_timer_stop": (_i, [_vp, C.POINTER(C.c_float)]),
+    "fdtd2d_time_launches": (_i, [_vp, _i, _i, C.POINTER(C.c_float)]),
     "fdtd2d_bytes_per_cell_step": (_i, [_vp]),
     "fdtd2d_device_ptr": (_vp, [_vp, _i]),
     "fdtd2d_version": (C.c_char_p, []),

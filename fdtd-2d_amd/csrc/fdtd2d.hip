@@ -1286,6 +1286,27 @@ int fdtd2d_timer_stop(fdtd2d_t *h, float *ms)
     return 0;
 }
 
+int fdtd2d_time_launches(fdtd2d_t *h, int nlaunch, int steps_each, float *ms)
+{
+    int rc = need_ready(h);
+    if (rc) return rc;
+    if (!ms || nlaunch < 1 || nlaunch > 256 || steps_each < 1) return fail(h, FDTD2D_E_ARG, "bad arguments");
+    std::vector<hipEvent_t> ev((size_t)2 * nlaunch, nullptr);
+    auto cleanup = [&]() { for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); };
+    for (hipEvent_t &e : ev)
+        if (hipEventCreate(&e) != hipSuccess) { cleanup(); return fail(h, FDTD2D_E_NOMEM, "hipEventCreate failed"); }
+    for (int n = 0; n < nlaunch && rc == 0; ++n) {
+        if (hipEventRecord(ev[2 * n], h->stream) != hipSuccess) rc = fail(h, FDTD2D_E_STATE, "hipEventRecord failed");
+        if (!rc) rc = fdtd2d_run(h, steps_each, 0, 0, nullptr);
+        if (!rc && hipEventRecord(ev[2 * n + 1], h->stream) != hipSuccess) rc = fail(h, FDTD2D_E_STATE, "hipEventRecord failed");
+    }
+    if (!rc && hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(h, FDTD2D_E_STATE, "stream sync failed");
+    for (int n = 0; n < nlaunch && rc == 0; ++n)
+        if (hipEventElapsedTime(&ms[n], ev[2 * n], ev[2 * n + 1]) != hipSuccess) rc = fail(h, FDTD2D_E_STATE, "hipEventElapsedTime failed");
+    cleanup();
+    return rc;
+}
+
 int fdtd2d_bytes_per_cell_step(const fdtd2d_t *h)
 {
     if (!h) return FDTD2D_E_ARG;

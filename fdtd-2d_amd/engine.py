@@ -312,6 +312,12 @@ class Engine:
         self._ck(self._lib.fdtd2d_timer_stop(self._h, C.byref(ms)))
         return float(ms.value)
 
+    def time_launches(self, nlaunch=32, steps_each=8):
+        """Milliseconds of each of `nlaunch` back-to-back passes (own HIP event pair each)."""
+        out = (C.c_float * int(nlaunch))()
+        self._ck(self._lib.fdtd2d_time_launches(self._h, int(nlaunch), int(steps_each), out))
+        return np.array(out[:], dtype=np.float64)
+
     @property
     def step_count(self) -> int:
         return self.info(_abi.INFO_STEP)

@@ -231,6 +231,12 @@ int fdtd2d_reduce(fdtd2d_t *h, int field, double *sum_sq, double *max_abs);
 int fdtd2d_timer_start(fdtd2d_t *h);
 int fdtd2d_timer_stop(fdtd2d_t *h, float *ms);
 
+/* Run `nlaunch` back-to-back passes of `steps_each` steps (no source) with one HIP event
+ * before and one after EACH of them on the handle's stream, wait, and store the elapsed
+ * milliseconds of every launch in ms[0..nlaunch-1].  For roofline measurements: this is the
+ * per-kernel duration rocprofv3's kernel trace reports.  nlaunch <= 256. */
+int fdtd2d_time_launches(fdtd2d_t *h, int nlaunch, int steps_each, float *ms);
+
 /* Algorithmic HBM bytes per cell-step of the current configuration (SURVEY.md
  * section 8 M2): 24 + 4 per non-uniform coefficient array, times sizeof(T)/4. */
 int fdtd2d_bytes_per_cell_step(const fdtd2d_t *h);

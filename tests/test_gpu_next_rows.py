@@ -77,3 +77,18 @@ def test_device_reductions(dtype):
             s, m = eng.reduce(name)
             assert m == np.abs(a).max()
             assert s == pytest.approx(np.sum(a.astype(np.float64) ** 2), rel=1e-12)
+
+
+def test_time_launches_and_counters():
+    """Measurement helpers of the C ABI: per-launch HIP-event timing and launch counters."""
+    import fdtd2d_amd as fd
+    with fd.Engine(512, 512, DT, DX, dtype=np.float32) as eng:
+        eng.set_materials()
+        p0 = eng.info(16)
+        ms = eng.time_launches(6, 8)
+        assert ms.shape == (6,) and np.all(ms > 0) and np.all(ms < 50)
+        assert eng.info(16) - p0 == 6 and eng.step_count == 48
+        assert eng.bytes_per_cell_step == 24
+        eng.timer_start()
+        eng.run(16)
+        assert 0 < eng.timer_stop() < 100

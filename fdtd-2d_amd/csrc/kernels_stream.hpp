@@ -462,6 +462,10 @@ void k_bulk(const PassParams<T> p)
     const bool edge = x0 < 5 || x0 + SW > p.g.C - 5;
     const bool src = p.src_row >= ra - 2 * NT && p.src_row < rb + NT && p.src_col >= x0 &&
                      p.src_col < x0 + SW;
+#ifdef STREAM_EXP_NO_GENERAL
+    stream_body<T, NT, CE_ARR, CH_ARR, false, V>(p, strip, ra, rb);   // timing experiment only
+    return;
+#endif
     if (edge || src)
         stream_body<T, NT, CE_ARR, CH_ARR, true, V>(p, strip, ra, rb);
     else

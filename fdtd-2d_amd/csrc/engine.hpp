@@ -1,0 +1,126 @@
+// Shared between the translation units of libfdtd2d.so: the handle, error helpers and the
+// entry point of the temporally blocked pass (defined per element type in pass_f32.hip /
+// pass_f64.hip so that the heavy kernel instantiations compile in parallel).
+#pragma once
+#include "../../include/fdtd2d.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "kernels_step.hpp"
+#include "kernels_stream.hpp"
+#include "kernels_pml.hpp"
+
+using fdtd::Geom;
+
+struct Range {
+    int lo, hi;
+};
+
+struct fdtd2d {
+    int rows = 0, cols = 0;      // global grid
+    int row0 = 0, nrows = 0;     // owned rows
+    int halo = 0;                // halo rows kept on each side (storage is symmetric)
+    int dtype = FDTD2D_F32, boundary = FDTD2D_BOUNDARY_MUR5, device = 0;
+    double dt = 0, dx = 0;
+    long long pitch = 0;         // elements per stored row
+    int stored = 0;              // stored rows = nrows + 2*halo
+    size_t esz = 4;              // element size
+    size_t field_bytes = 0;      // bytes of one stored field (without guard)
+
+    void *ez[2] = {nullptr, nullptr};
+    int cur = 0;                 // ez[cur] is the current Ez
+    void *hxb[2] = {nullptr, nullptr}, *hyb[2] = {nullptr, nullptr};
+    int hcur = 0;                // hxb[hcur], hyb[hcur] are the current Hx, Hy
+    void *ce = nullptr, *ch = nullptr;    // coefficient arrays (nullptr when uniform)
+    void *ezxb[2] = {nullptr, nullptr};   // PML only: the x-part of the split Ez (set follows hcur)
+    void *pml = nullptr;                  // PML only: 4 row + 4 column factor arrays, back to back
+    bool have_pml = false;
+    int pml_L = 0;
+    int pml_short_rows = 16;     // band height of the layer waves (FDTD2D_PML_SHORT overrides)
+    int nfields() const { return boundary == FDTD2D_BOUNDARY_PML ? 4 : 3; }
+    bool have_mat = false, ce_uniform = true, ch_uniform = true;
+    double ce_u = 0, ch_u = 0;   // uniform coefficients, already rounded to T
+    double k_mur = 0;            // Mur factor, already rounded to T
+    double eps_min = 0, mu_min = 0;
+
+    Range ev{0, 0}, hv{0, 0};    // global rows on which Ez / (Hx,Hy) are current
+    long long step = 0;
+    long long pass_launches = 0, step_launches = 0;
+    // a pass issued in pieces (fdtd2d_pass_rows) and not yet committed
+    int pend_nt = 0;
+    std::vector<Range> pend_done;
+
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    hipStream_t side_stream = nullptr;   // zone tiles run here, concurrently with the bulk
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    void *trash = nullptr;       // 4 KiB: destination of masked-off stores in k_bulk
+    void *scratch = nullptr;     // device scratch for snapshots / reduction partials
+    size_t scratch_bytes = 0;
+    std::string err;
+
+    bool top() const { return row0 == 0; }
+    bool bottom() const { return row0 + nrows == rows; }
+    int row_base() const { return row0 - halo; }
+    int store_lo() const { return std::max(0, row0 - halo); }
+    int store_hi() const { return std::min(rows, row0 + nrows + halo); }
+    Geom geom() const { return Geom{rows, cols, row_base(), pitch}; }
+    void *ezx() const { return ezxb[hcur]; }
+    void *hx() const { return hxb[hcur]; }
+    void *hy() const { return hyb[hcur]; }
+    int stream_band_rows = 0;    // 0 = heuristic (FDTD2D_BAND_ROWS overrides)
+    int zone_split = -1;         // -1: by launch size; 0/1: force fused / side-stream zones (FDTD2D_ZONE_SPLIT)
+    int edge_band_div = 1;       // edge strips use band_rows / this (FDTD2D_EDGE_DIV; measured: no gain)
+    int max_nt = 8;              // longest pass; FDTD2D_MAX_NT / set_option override (0: step kernels only)
+};
+
+
+namespace fdtd_host {
+
+extern thread_local std::string g_create_error;
+
+inline int fail(fdtd2d *h, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf;
+    else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(h, expr)                                                                        \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fdtd_host::fail((h), -(1000 + (int)e_), "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+template <class T> fdtd::PmlFactors<T> pml_factors(const fdtd2d *h)
+{
+    const T *b = (const T *)h->pml;
+    const size_t R = h->rows, C = h->cols;
+    return fdtd::PmlFactors<T>{b, b + R, b + 2 * R, b + 3 * R, b + 4 * R, b + 4 * R + C, b + 4 * R + 2 * C,
+                               b + 4 * R + 3 * C, h->pml_L, h->rows, h->cols};
+}
+
+
+// Can a pass of nt steps run from the current state?  Fills the row range of the bulk.
+bool pass_geometry(const fdtd2d *h, int nt, int *band_lo, int *band_hi);
+
+// One pass of nt steps (or the rows [band_lo, band_hi) of it); see pass_impl.hpp.
+template <class T>
+int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, int src_row, int src_col,
+                const double *amps, bool ztop, bool zbot, bool commit, int full_lo, int full_hi);
+extern template int launch_pass<float>(fdtd2d *, int, int, int, int, int, const double *, bool, bool, bool, int, int);
+extern template int launch_pass<double>(fdtd2d *, int, int, int, int, int, const double *, bool, bool, bool, int, int);
+
+}  // namespace fdtd_host

@@ -1,112 +1,18 @@
 // libfdtd2d.so -- host side of the C ABI declared in include/fdtd2d.h.
 // MI355X (gfx950) only.  No CPU fallback: every compute entry point needs the device.
-#include "../../include/fdtd2d.h"
+#include "engine.hpp"
 
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
 #include <cmath>
-#include <cstdarg>
-#include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <string>
-#include <vector>
 
-#include "kernels_step.hpp"
-#include "kernels_stream.hpp"
-#include "kernels_pml.hpp"
-
-using fdtd::Geom;
-
-namespace {
-
+namespace fdtd_host {
 thread_local std::string g_create_error = "";
-
-struct Range {
-    int lo, hi;
-};
-
-}  // namespace
-
-struct fdtd2d {
-    int rows = 0, cols = 0;      // global grid
-    int row0 = 0, nrows = 0;     // owned rows
-    int halo = 0;                // halo rows kept on each side (storage is symmetric)
-    int dtype = FDTD2D_F32, boundary = FDTD2D_BOUNDARY_MUR5, device = 0;
-    double dt = 0, dx = 0;
-    long long pitch = 0;         // elements per stored row
-    int stored = 0;              // stored rows = nrows + 2*halo
-    size_t esz = 4;              // element size
-    size_t field_bytes = 0;      // bytes of one stored field (without guard)
-
-    void *ez[2] = {nullptr, nullptr};
-    int cur = 0;                 // ez[cur] is the current Ez
-    void *hxb[2] = {nullptr, nullptr}, *hyb[2] = {nullptr, nullptr};
-    int hcur = 0;                // hxb[hcur], hyb[hcur] are the current Hx, Hy
-    void *ce = nullptr, *ch = nullptr;    // coefficient arrays (nullptr when uniform)
-    void *ezxb[2] = {nullptr, nullptr};   // PML only: the x-part of the split Ez (set follows hcur)
-    void *pml = nullptr;                  // PML only: 4 row + 4 column factor arrays, back to back
-    bool have_pml = false;
-    int pml_L = 0;
-    int pml_short_rows = 16;     // band height of the layer waves (FDTD2D_PML_SHORT overrides)
-    int nfields() const { return boundary == FDTD2D_BOUNDARY_PML ? 4 : 3; }
-    bool have_mat = false, ce_uniform = true, ch_uniform = true;
-    double ce_u = 0, ch_u = 0;   // uniform coefficients, already rounded to T
-    double k_mur = 0;            // Mur factor, already rounded to T
-    double eps_min = 0, mu_min = 0;
-
-    Range ev{0, 0}, hv{0, 0};    // global rows on which Ez / (Hx,Hy) are current
-    long long step = 0;
-    long long pass_launches = 0, step_launches = 0;
-    // a pass issued in pieces (fdtd2d_pass_rows) and not yet committed
-    int pend_nt = 0;
-    std::vector<Range> pend_done;
-
-    hipStream_t own_stream = nullptr, stream = nullptr;
-    hipEvent_t t0 = nullptr, t1 = nullptr;
-    hipStream_t side_stream = nullptr;   // zone tiles run here, concurrently with the bulk
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    void *trash = nullptr;       // 4 KiB: destination of masked-off stores in k_bulk
-    void *scratch = nullptr;     // device scratch for snapshots / reduction partials
-    size_t scratch_bytes = 0;
-    std::string err;
-
-    bool top() const { return row0 == 0; }
-    bool bottom() const { return row0 + nrows == rows; }
-    int row_base() const { return row0 - halo; }
-    int store_lo() const { return std::max(0, row0 - halo); }
-    int store_hi() const { return std::min(rows, row0 + nrows + halo); }
-    Geom geom() const { return Geom{rows, cols, row_base(), pitch}; }
-    void *ezx() const { return ezxb[hcur]; }
-    void *hx() const { return hxb[hcur]; }
-    void *hy() const { return hyb[hcur]; }
-    int stream_band_rows = 0;    // 0 = heuristic (FDTD2D_BAND_ROWS overrides)
-    int zone_split = -1;         // -1: by launch size; 0/1: force fused / side-stream zones (FDTD2D_ZONE_SPLIT)
-    int edge_band_div = 1;       // edge strips use band_rows / this (FDTD2D_EDGE_DIV; measured: no gain)
-    int max_nt = 8;              // longest pass; FDTD2D_MAX_NT / set_option override (0: step kernels only)
-};
-
-namespace {
-
-int fail(fdtd2d *h, int code, const char *fmt, ...)
-{
-    char buf[512];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
-    va_end(ap);
-    if (h) h->err = buf;
-    else g_create_error = buf;
-    return code;
 }
 
-#define HIPCHK(h, expr)                                                                        \
-    do {                                                                                       \
-        hipError_t e_ = (expr);                                                                \
-        if (e_ != hipSuccess)                                                                  \
-            return fail((h), -(1000 + (int)e_), "%s failed: %s", #expr, hipGetErrorString(e_)); \
-    } while (0)
+using namespace fdtd_host;
+
+namespace {
 
 int use_device(fdtd2d *h)
 {
@@ -223,14 +129,6 @@ int zero_fields(fdtd2d *h)
 }
 
 // ---- launches --------------------------------------------------------------------------
-
-template <class T> fdtd::PmlFactors<T> pml_factors(const fdtd2d *h)
-{
-    const T *b = (const T *)h->pml;
-    const size_t R = h->rows, C = h->cols;
-    return fdtd::PmlFactors<T>{b, b + R, b + 2 * R, b + 3 * R, b + 4 * R, b + 4 * R + C, b + 4 * R + 2 * C,
-                               b + 4 * R + 3 * C, h->pml_L, h->rows, h->cols};
-}
 
 template <class T> int launch_h(fdtd2d *h, int lo, int hi)
 {
@@ -373,8 +271,9 @@ int do_add_point(fdtd2d *h, int row, int col, double amp)
 }
 
 
-// ---- temporally blocked passes (kernels_stream.hpp) ----------------------------------------
+}  // namespace
 
+namespace fdtd_host {
 // Can a pass of nt steps run from the current state?  Fills the row range of the bulk.
 bool pass_geometry(const fdtd2d *h, int nt, int *band_lo, int *band_hi)
 {
@@ -412,146 +311,9 @@ bool pass_geometry(const fdtd2d *h, int nt, int *band_lo, int *band_hi)
     return true;
 }
 
-template <class T, int NT, bool CE_ARR, bool CH_ARR, int V = fdtd::Vec<T>::N>
-int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
-{
-    using D = fdtd::ZoneDims<NT>;
-    const int region = std::max(0, p.band_hi - p.band_lo);
-    p.nbands = (region + p.band_rows - 1) / p.band_rows;
-    p.band_rows_e = std::max(1, h->edge_band_div > 0 ? p.band_rows / h->edge_band_div : p.band_rows);
-    p.nbands_e = (region + p.band_rows_e - 1) / p.band_rows_e;
-    p.zone_tiles = (h->cols + D::WZ - 1) / D::WZ;
-    // launch order: zone tiles, 2 edge-strip slots (the second stays empty with one strip),
-    // then strips 1 .. nstrips-2
-    const long long bulk = 2LL * p.nbands_e + (long long)p.nbands * std::max(0, p.nstrips - 2);
-    const long long zones = (long long)(p.zone_top + p.zone_bot) * p.zone_tiles;
-    if (bulk + zones == 0) return 0;
-    // Small launches: zone tiles as k_zone on the side stream (ordered behind what is already
-    // on h->stream; everything later on h->stream waits for both).  Large launches: fused.
-    const bool split = zones > 0 && (h->zone_split < 0 ? bulk < 1600 : h->zone_split != 0);
-    p.fused_zones = zones > 0 && !split;
-    if (split) {
-        HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
-        HIPCHK(h, hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
-        hipLaunchKernelGGL((fdtd::k_zone<T, NT, CE_ARR, CH_ARR>), dim3((unsigned)zones),
-                           dim3(fdtd::PASS_THREADS), 0, h->side_stream, p);
-        HIPCHK(h, hipGetLastError());
-        HIPCHK(h, hipEventRecord(h->ev_join, h->side_stream));
-    }
-    const long long blocks = bulk + (p.fused_zones ? zones : 0);
-    if (blocks > 0) {
-        hipLaunchKernelGGL((fdtd::k_bulk<T, NT, CE_ARR, CH_ARR, V>), dim3((unsigned)blocks), dim3(64), 0,
-                           h->stream, p);
-        HIPCHK(h, hipGetLastError());
-    }
-    if (split) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
-    h->pass_launches++;
-    return 0;
-}
+}  // namespace fdtd_host
 
-template <class T, int NT> int launch_pass_nt(fdtd2d *h, fdtd::PassParams<T> &p)
-{
-    if (h->ce_uniform && h->ch_uniform) return launch_pass_impl<T, NT, false, false>(h, p);
-    if constexpr (NT > 8)   // the coefficient rows do not fit the register budget beyond 8 levels
-        return fail(h, FDTD2D_E_ARG, "passes longer than 8 steps need uniform materials");
-    else {
-    if (!h->ce_uniform && h->ch_uniform) return launch_pass_impl<T, NT, true, false>(h, p);
-    if (h->ce_uniform && !h->ch_uniform) return launch_pass_impl<T, NT, false, true>(h, p);
-    return launch_pass_impl<T, NT, true, true>(h, p);
-    }
-}
-
-// One pass of nt in {1,2,4,8} steps; amps = nt amplitudes or nullptr.
-template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, int src_row,
-                                   int src_col, const double *amps, bool ztop, bool zbot,
-                                   bool commit, int full_lo, int full_hi)
-{
-    // (k_bulk also instantiates with 2 columns per lane -- 86 VGPRs, 4-5 waves per SIMD -- but
-    // that measured 20 % slower than 4 columns: profiles/r01_kpass_ablation.txt)
-    constexpr int V = fdtd::Vec<T>::N;
-    const int OW = 64 * V - 2 * fdtd::stream_hc(nt);
-    fdtd::PassParams<T> p;
-    p.ez_in = (const T *)h->ez[h->cur];
-    p.hx_in = (const T *)h->hxb[h->hcur];
-    p.hy_in = (const T *)h->hyb[h->hcur];
-    p.ez_out = (T *)h->ez[h->cur ^ 1];
-    p.hx_out = (T *)h->hxb[h->hcur ^ 1];
-    p.hy_out = (T *)h->hyb[h->hcur ^ 1];
-    p.ce = (const T *)h->ce;
-    p.ch = (const T *)h->ch;
-    p.ce_u = (T)h->ce_u;
-    p.ch_u = (T)h->ch_u;
-    p.k = (T)h->k_mur;
-    p.g = h->geom();
-    p.band_lo = band_lo;
-    p.band_hi = band_hi;
-    p.nstrips = (h->cols + OW - 1) / OW;
-    int br = h->stream_band_rows;
-    if (br <= 0) {
-        // Measured on MI355X (interleaved A/B, profiles/r01_band_sweep.txt): the pass is fastest
-        // with about one wave per wave slot (1024 SIMDs x 3 waves) and bands of 16..128 rows:
-        // 16 rows at 2048^2, 24 at 4096^2, 64-96 at 8192^2, 96-192 at 16384^2.  Shorter bands pay
-        // too much pipeline fill, taller ones leave SIMDs without a second wave to switch to.
-        const int region = std::max(0, band_hi - band_lo);
-        const int want = std::max(1, (3072 + p.nstrips - 1) / p.nstrips);
-        br = std::min(std::max(region / want, 16), 128);
-    }
-    p.band_rows = std::max(br, 1);
-    p.zone_top = ztop;
-    p.zone_bot = zbot;
-    p.trash = (T *)h->trash;
-    p.src_row = amps ? src_row : -1;
-    p.src_col = amps ? src_col : -1;
-    for (int s = 0; s < fdtd::STREAM_MAX_NT; ++s) p.amp[s] = (amps && s < nt) ? amps[s] : 0.0;
-    int rc;
-    if (h->boundary == FDTD2D_BOUNDARY_PML) {
-        p.zone_top = p.zone_bot = 0;
-        p.zone_tiles = 0;
-        const int region = std::max(0, p.band_hi - p.band_lo);
-        p.nbands = (region + p.band_rows - 1) / p.band_rows;
-        fdtd::PmlPass<T> q{pml_factors<T>(h), (const T *)h->ezxb[h->hcur], (T *)h->ezxb[h->hcur ^ 1],
-                           0, 0, 0, 0, 0, 0, 0};
-        // rows whose 8-step cone can touch the top / bottom layer: [0, L+1+16) and the mirror
-        const int reach = h->pml_L + 1 + 2 * nt;
-        q.short_rows = h->pml_short_rows;
-        auto up = [&](int x) { return (x + q.short_rows - 1) / q.short_rows * q.short_rows; };
-        q.a_hi = std::min(p.band_hi, std::max(p.band_lo, h->top() ? p.band_lo + up(reach - p.band_lo) : p.band_lo));
-        q.c_lo = std::max(q.a_hi, std::min(p.band_hi, h->bottom() ? p.band_hi - up(p.band_hi - (h->rows - reach)) : p.band_hi));
-        q.n1 = (region + q.short_rows - 1) / q.short_rows;
-        q.nA = (q.a_hi - p.band_lo + q.short_rows - 1) / q.short_rows;
-        q.nC = (p.band_hi - q.c_lo + q.short_rows - 1) / q.short_rows;
-        q.nB = (std::max(0, q.c_lo - q.a_hi) + p.band_rows - 1) / p.band_rows;
-        const int inner = std::max(0, p.nstrips - 2);
-        const long long blocks = 2LL * q.n1 + (long long)inner * (q.nA + q.nC + q.nB);
-        if (blocks > 0) {
-            if (h->ce_uniform)
-                hipLaunchKernelGGL((fdtd::k_pass_pml<T, false>), dim3((unsigned)blocks), dim3(64), 0, h->stream, p, q);
-            else
-                hipLaunchKernelGGL((fdtd::k_pass_pml<T, true>), dim3((unsigned)blocks), dim3(64), 0, h->stream, p, q);
-            HIPCHK(h, hipGetLastError());
-            h->pass_launches++;
-        }
-        rc = 0;
-    } else
-    switch (nt) {
-    case 12:
-        if constexpr (sizeof(T) == 4) { rc = launch_pass_nt<T, 12>(h, p); break; }
-        return fail(h, FDTD2D_E_ARG, "12-step passes are built for float32 only");
-    case 8: rc = launch_pass_nt<T, 8>(h, p); break;
-    case 4: rc = launch_pass_nt<T, 4>(h, p); break;
-    case 2: rc = launch_pass_nt<T, 2>(h, p); break;
-    case 1: rc = launch_pass_nt<T, 1>(h, p); break;
-    default: return fail(h, FDTD2D_E_ARG, "unsupported pass length %d", nt);
-    }
-    if (rc) return rc;
-    if (commit) {
-        h->cur ^= 1;
-        h->hcur ^= 1;
-        h->ev = h->hv = Range{h->top() ? 0 : full_lo, h->bottom() ? h->rows : full_hi};
-        h->step += nt;
-    }
-    return 0;
-}
+namespace {
 
 template <class T> int make_coef(fdtd2d *h, void *arr)
 {

@@ -1,0 +1,150 @@
+// Host side of the temporally blocked pass, instantiated once per element type
+// (pass_f32.hip, pass_f64.hip).
+#pragma once
+#include "engine.hpp"
+
+namespace fdtd_host {
+
+template <class T, int NT, bool CE_ARR, bool CH_ARR, int V = fdtd::Vec<T>::N>
+int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
+{
+    using D = fdtd::ZoneDims<NT>;
+    const int region = std::max(0, p.band_hi - p.band_lo);
+    p.nbands = (region + p.band_rows - 1) / p.band_rows;
+    p.band_rows_e = std::max(1, h->edge_band_div > 0 ? p.band_rows / h->edge_band_div : p.band_rows);
+    p.nbands_e = (region + p.band_rows_e - 1) / p.band_rows_e;
+    p.zone_tiles = (h->cols + D::WZ - 1) / D::WZ;
+    // launch order: zone tiles, 2 edge-strip slots (the second stays empty with one strip),
+    // then strips 1 .. nstrips-2
+    const long long bulk = 2LL * p.nbands_e + (long long)p.nbands * std::max(0, p.nstrips - 2);
+    const long long zones = (long long)(p.zone_top + p.zone_bot) * p.zone_tiles;
+    if (bulk + zones == 0) return 0;
+    // Small launches: zone tiles as k_zone on the side stream (ordered behind what is already
+    // on h->stream; everything later on h->stream waits for both).  Large launches: fused.
+    const bool split = zones > 0 && (h->zone_split < 0 ? bulk < 1600 : h->zone_split != 0);
+    p.fused_zones = zones > 0 && !split;
+    if (split) {
+        HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
+        HIPCHK(h, hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
+        hipLaunchKernelGGL((fdtd::k_zone<T, NT, CE_ARR, CH_ARR>), dim3((unsigned)zones),
+                           dim3(fdtd::PASS_THREADS), 0, h->side_stream, p);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipEventRecord(h->ev_join, h->side_stream));
+    }
+    const long long blocks = bulk + (p.fused_zones ? zones : 0);
+    if (blocks > 0) {
+        hipLaunchKernelGGL((fdtd::k_bulk<T, NT, CE_ARR, CH_ARR, V>), dim3((unsigned)blocks), dim3(64), 0,
+                           h->stream, p);
+        HIPCHK(h, hipGetLastError());
+    }
+    if (split) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
+    h->pass_launches++;
+    return 0;
+}
+
+template <class T, int NT> int launch_pass_nt(fdtd2d *h, fdtd::PassParams<T> &p)
+{
+    if (h->ce_uniform && h->ch_uniform) return launch_pass_impl<T, NT, false, false>(h, p);
+    if constexpr (NT > 8)   // the coefficient rows do not fit the register budget beyond 8 levels
+        return fail(h, FDTD2D_E_ARG, "passes longer than 8 steps need uniform materials");
+    else {
+    if (!h->ce_uniform && h->ch_uniform) return launch_pass_impl<T, NT, true, false>(h, p);
+    if (h->ce_uniform && !h->ch_uniform) return launch_pass_impl<T, NT, false, true>(h, p);
+    return launch_pass_impl<T, NT, true, true>(h, p);
+    }
+}
+
+// One pass of nt in {1,2,4,8} steps; amps = nt amplitudes or nullptr.
+template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, int src_row,
+                                   int src_col, const double *amps, bool ztop, bool zbot,
+                                   bool commit, int full_lo, int full_hi)
+{
+    // (k_bulk also instantiates with 2 columns per lane -- 86 VGPRs, 4-5 waves per SIMD -- but
+    // that measured 20 % slower than 4 columns: profiles/r01_kpass_ablation.txt)
+    constexpr int V = fdtd::Vec<T>::N;
+    const int OW = 64 * V - 2 * fdtd::stream_hc(nt);
+    fdtd::PassParams<T> p;
+    p.ez_in = (const T *)h->ez[h->cur];
+    p.hx_in = (const T *)h->hxb[h->hcur];
+    p.hy_in = (const T *)h->hyb[h->hcur];
+    p.ez_out = (T *)h->ez[h->cur ^ 1];
+    p.hx_out = (T *)h->hxb[h->hcur ^ 1];
+    p.hy_out = (T *)h->hyb[h->hcur ^ 1];
+    p.ce = (const T *)h->ce;
+    p.ch = (const T *)h->ch;
+    p.ce_u = (T)h->ce_u;
+    p.ch_u = (T)h->ch_u;
+    p.k = (T)h->k_mur;
+    p.g = h->geom();
+    p.band_lo = band_lo;
+    p.band_hi = band_hi;
+    p.nstrips = (h->cols + OW - 1) / OW;
+    int br = h->stream_band_rows;
+    if (br <= 0) {
+        // Measured on MI355X (interleaved A/B, profiles/r01_band_sweep.txt): the pass is fastest
+        // with about one wave per wave slot (1024 SIMDs x 3 waves) and bands of 16..128 rows:
+        // 16 rows at 2048^2, 24 at 4096^2, 64-96 at 8192^2, 96-192 at 16384^2.  Shorter bands pay
+        // too much pipeline fill, taller ones leave SIMDs without a second wave to switch to.
+        const int region = std::max(0, band_hi - band_lo);
+        const int want = std::max(1, (3072 + p.nstrips - 1) / p.nstrips);
+        br = std::min(std::max(region / want, 16), 128);
+    }
+    p.band_rows = std::max(br, 1);
+    p.zone_top = ztop;
+    p.zone_bot = zbot;
+    p.trash = (T *)h->trash;
+    p.src_row = amps ? src_row : -1;
+    p.src_col = amps ? src_col : -1;
+    for (int s = 0; s < fdtd::STREAM_MAX_NT; ++s) p.amp[s] = (amps && s < nt) ? amps[s] : 0.0;
+    int rc;
+    if (h->boundary == FDTD2D_BOUNDARY_PML) {
+        p.zone_top = p.zone_bot = 0;
+        p.zone_tiles = 0;
+        const int region = std::max(0, p.band_hi - p.band_lo);
+        p.nbands = (region + p.band_rows - 1) / p.band_rows;
+        fdtd::PmlPass<T> q{pml_factors<T>(h), (const T *)h->ezxb[h->hcur], (T *)h->ezxb[h->hcur ^ 1],
+                           0, 0, 0, 0, 0, 0, 0};
+        // rows whose 8-step cone can touch the top / bottom layer: [0, L+1+16) and the mirror
+        const int reach = h->pml_L + 1 + 2 * nt;
+        q.short_rows = h->pml_short_rows;
+        auto up = [&](int x) { return (x + q.short_rows - 1) / q.short_rows * q.short_rows; };
+        q.a_hi = std::min(p.band_hi, std::max(p.band_lo, h->top() ? p.band_lo + up(reach - p.band_lo) : p.band_lo));
+        q.c_lo = std::max(q.a_hi, std::min(p.band_hi, h->bottom() ? p.band_hi - up(p.band_hi - (h->rows - reach)) : p.band_hi));
+        q.n1 = (region + q.short_rows - 1) / q.short_rows;
+        q.nA = (q.a_hi - p.band_lo + q.short_rows - 1) / q.short_rows;
+        q.nC = (p.band_hi - q.c_lo + q.short_rows - 1) / q.short_rows;
+        q.nB = (std::max(0, q.c_lo - q.a_hi) + p.band_rows - 1) / p.band_rows;
+        const int inner = std::max(0, p.nstrips - 2);
+        const long long blocks = 2LL * q.n1 + (long long)inner * (q.nA + q.nC + q.nB);
+        if (blocks > 0) {
+            if (h->ce_uniform)
+                hipLaunchKernelGGL((fdtd::k_pass_pml<T, false>), dim3((unsigned)blocks), dim3(64), 0, h->stream, p, q);
+            else
+                hipLaunchKernelGGL((fdtd::k_pass_pml<T, true>), dim3((unsigned)blocks), dim3(64), 0, h->stream, p, q);
+            HIPCHK(h, hipGetLastError());
+            h->pass_launches++;
+        }
+        rc = 0;
+    } else
+    switch (nt) {
+    case 12:
+        if constexpr (sizeof(T) == 4) { rc = launch_pass_nt<T, 12>(h, p); break; }
+        return fail(h, FDTD2D_E_ARG, "12-step passes are built for float32 only");
+    case 8: rc = launch_pass_nt<T, 8>(h, p); break;
+    case 4: rc = launch_pass_nt<T, 4>(h, p); break;
+    case 2: rc = launch_pass_nt<T, 2>(h, p); break;
+    case 1: rc = launch_pass_nt<T, 1>(h, p); break;
+    default: return fail(h, FDTD2D_E_ARG, "unsupported pass length %d", nt);
+    }
+    if (rc) return rc;
+    if (commit) {
+        h->cur ^= 1;
+        h->hcur ^= 1;
+        h->ev = h->hv = Range{h->top() ? 0 : full_lo, h->bottom() ? h->rows : full_hi};
+        h->step += nt;
+    }
+    return 0;
+}
+
+
+}  // namespace fdtd_host

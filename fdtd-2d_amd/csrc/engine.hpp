@@ -15,6 +15,7 @@
 #include "kernels_step.hpp"
 #include "kernels_stream.hpp"
 #include "kernels_pml.hpp"
+#include "kernels_split.hpp"
 
 using fdtd::Geom;
 
@@ -75,6 +76,14 @@ struct fdtd2d {
     void *hx() const { return hxb[hcur]; }
     void *hy() const { return hyb[hcur]; }
     int stream_band_rows = 0;    // 0 = heuristic (FDTD2D_BAND_ROWS overrides)
+    int level_split = -1;        // k_bulk_split for 8-step passes with uniform materials: -1 = on slabs
+                                 // below ~10 M cells (measured faster there), 0 never, 1 always
+    bool use_level_split(int nt, int band_lo, int band_hi) const
+    {
+        if (nt != 8 || !ce_uniform || !ch_uniform || boundary != FDTD2D_BOUNDARY_MUR5) return false;
+        if (level_split >= 0) return level_split != 0;
+        return (long long)std::max(0, band_hi - band_lo) * cols < 10000000LL;
+    }
     int zone_split = -1;         // -1: by launch size; 0/1: force fused / side-stream zones (FDTD2D_ZONE_SPLIT)
     int edge_band_div = 1;       // edge strips use band_rows / this (FDTD2D_EDGE_DIV; measured: no gain)
     int max_nt = 8;              // longest pass; FDTD2D_MAX_NT / set_option override (0: step kernels only)

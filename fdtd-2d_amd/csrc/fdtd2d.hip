@@ -432,6 +432,7 @@ int create_impl(fdtd2d_t **out, int rows, int cols, int row0, int nrows, int hal
     if (const char *e2 = std::getenv("FDTD2D_MAX_NT")) h->max_nt = std::atoi(e2);
     if (const char *e2 = std::getenv("FDTD2D_EDGE_DIV")) h->edge_band_div = std::max(1, std::atoi(e2));
     if (const char *e2 = std::getenv("FDTD2D_ZONE_SPLIT")) h->zone_split = std::atoi(e2);
+    if (const char *e2 = std::getenv("FDTD2D_LEVEL_SPLIT")) h->level_split = std::atoi(e2);
     if (const char *e2 = std::getenv("FDTD2D_PML_SHORT")) h->pml_short_rows = std::max(1, std::atoi(e2));
     rc = zero_fields(h);
     if (rc) return bail(rc);
@@ -887,6 +888,10 @@ int fdtd2d_set_option(fdtd2d_t *h, int option, long long value)
     case FDTD2D_OPT_BAND_ROWS:
         if (value < 0) return fail(h, FDTD2D_E_ARG, "band rows must be >= 0");
         h->stream_band_rows = (int)value;
+        return 0;
+    case FDTD2D_OPT_LEVEL_SPLIT:
+        if (value < -1 || value > 1) return fail(h, FDTD2D_E_ARG, "level split must be -1, 0 or 1");
+        h->level_split = (int)value;
         return 0;
     case FDTD2D_OPT_ZONE_SPLIT:
         if (value < -1 || value > 1) return fail(h, FDTD2D_E_ARG, "zone split must be -1, 0 or 1");

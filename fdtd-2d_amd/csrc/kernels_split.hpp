@@ -1,0 +1,251 @@
+// Level-split variant of the temporally blocked pass (uniform materials, 8 steps per launch).
+//
+// k_bulk (kernels_stream.hpp) lets ONE wave carry all 8 time levels of a (band, strip): 12 row
+// slots = 144 VGPRs, 3 waves per SIMD, and to keep ~3000 waves busy on a 4096^2 grid the bands
+// can only be ~24 rows tall, so every band re-reads 16 neighbour rows (HBM reads 2x ideal).
+// Here a workgroup of NW = 4 waves shares one (band, strip): wave w advances levels 2w+1 and
+// 2w+2 and hands each finished row to wave w+1 through LDS (double-buffered by tick parity,
+// one s_barrier per tick).  Each wave then needs 4-6 slots (<= 100 VGPRs, 5 waves per SIMD),
+// and for the same number of waves the bands are 4x taller: less re-reading, less redundant
+// arithmetic.  The arithmetic per cell is the same as everywhere else (value-identical).
+//
+// Tick tau of the workgroup: wave w takes as input row r = tau - 3w at level 2w (wave 0 from
+// HBM with a 2-row prefetch, the others from the LDS buffer wave w-1 filled in the previous
+// tick), updates row r-1 to level 2w+1 and row r-2 to level 2w+2 in place (same slot ring as
+// k_bulk), and hands row r-2 on (the last wave stores it).  Three lag rows per wave: the
+// level-8 row leaves at tick r+11.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kernels_stream.hpp"
+
+namespace fdtd {
+
+constexpr int SPLIT_NW = 4;                    // waves per workgroup
+constexpr int SPLIT_NT = 8;                    // steps per pass
+constexpr int SPLIT_LV = SPLIT_NT / SPLIT_NW;  // levels per wave
+constexpr int SPLIT_LAG = SPLIT_LV + 1;        // tick offset between consecutive waves
+
+// per-lane constants of a strip + the level update (same operations as stream_body)
+template <class T, bool GENERAL, int V> struct StripMath {
+    using VT = VecN<T, V>;
+    struct Row {
+        VT e, x, y;
+    };
+    const PassParams<T> &p;
+    int j0;
+    bool ld_ok, has_l, has_r;
+    VT ceu, chu;
+    bool in_l[V], in_r[V];
+
+    __device__ __forceinline__ StripMath(const PassParams<T> &pp, int x0, int lane) : p(pp)
+    {
+        constexpr int SW = 64 * V;
+        j0 = x0 + V * lane;
+        ld_ok = j0 >= 0 && j0 < p.g.C;
+        has_l = GENERAL && x0 < 5;
+        has_r = GENERAL && x0 + SW > p.g.C - 5;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const int j = j0 + v;
+            const bool mh = j >= 0 && j <= p.g.C - 2, me = j >= 1 && j <= p.g.C - 2;
+            ceu.v[v] = GENERAL ? (me ? p.ce_u : T(0)) : p.ce_u;
+            chu.v[v] = GENERAL ? (mh ? p.ch_u : T(0)) : p.ch_u;
+            in_l[v] = j >= 0 && j < 5;
+            in_r[v] = j >= p.g.C - 5 && j < p.g.C;
+        }
+    }
+
+    // row i: level t-1 -> t, in place.  nx = row i+1 at level t-1, pvx = Hx of row i-1 at level t
+    __device__ __forceinline__ void level(Row &c, const VT &nxe, const VT &pvx, int t, int i) const
+    {
+        const T e_next_lane = from_next(c.e.v[0]);
+        VT po;
+        if (GENERAL) po = c.e;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const T ch = GENERAL ? chu.v[v] : p.ch_u;
+            const T right = (v + 1 < V) ? c.e.v[v + 1] : e_next_lane;
+            c.x.v[v] = c.x.v[v] - ch * (nxe.v[v] - c.e.v[v]);
+            c.y.v[v] = c.y.v[v] + ch * (right - c.e.v[v]);
+        }
+        const T hy_prev_lane = from_prev(c.y.v[V - 1]);
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const T ce = GENERAL ? ceu.v[v] : p.ce_u;
+            const T left = (v > 0) ? c.y.v[v - 1] : hy_prev_lane;
+            c.e.v[v] = c.e.v[v] + ((c.y.v[v] - left) - (c.x.v[v] - pvx.v[v])) * ce;
+        }
+        if (GENERAL) {
+            if (has_l) {
+                const T a_next = from_next(c.e.v[0]);
+                VT out;
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    const T pr = (v + 1 < V) ? po.v[v + 1] : e_next_lane;
+                    const T ar = (v + 1 < V) ? c.e.v[v + 1] : a_next;
+                    out.v[v] = in_l[v] ? pr + p.k * (ar - po.v[v]) : c.e.v[v];
+                }
+                c.e = out;
+            }
+            if (has_r) {
+                const T a_prev = from_prev(c.e.v[V - 1]), p_prev = from_prev(po.v[V - 1]);
+                VT out;
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    const T pl = (v > 0) ? po.v[v - 1] : p_prev;
+                    const T al = (v > 0) ? c.e.v[v - 1] : a_prev;
+                    out.v[v] = in_r[v] ? pl + p.k * (al - po.v[v]) : c.e.v[v];
+                }
+                c.e = out;
+            }
+            if (i == p.src_row) {
+                const double amp = p.amp[t - 1];
+#pragma unroll
+                for (int v = 0; v < V; ++v)
+                    if (j0 + v == p.src_col) c.e.v[v] = (T)((double)c.e.v[v] + amp);
+            }
+        }
+    }
+};
+
+// ROLE 0: first wave (HBM -> LDS), 1: middle (LDS -> LDS), 2: last (LDS -> HBM)
+template <class T, bool GENERAL, int ROLE, int V>
+__device__ __forceinline__ void split_body(const PassParams<T> &p, const int strip, const int ra,
+                                           const int rb, const int w, VecN<T, V> *lds)
+{
+    using M = StripMath<T, GENERAL, V>;
+    using Row = typename M::Row;
+    constexpr int NT = SPLIT_NT, LV = SPLIT_LV, LAG = SPLIT_LAG;
+    constexpr int HC = stream_hc(NT);
+    constexpr int SW = 64 * V, OW = SW - 2 * HC;
+    constexpr int PF = ROLE == 0 ? 2 : 0;       // only the first wave hides HBM latency
+    constexpr int S = LV + 2 + PF;              // ring of row slots, tick loop unrolled S times
+    const Geom g = p.g;
+    const int lane = threadIdx.x & 63;
+    const int x0 = strip_x0<T, NT, V>(p, strip);
+    const M m(p, x0, lane);
+    const int j0 = m.j0;
+    const bool st_ok = m.ld_ok && j0 >= strip * OW && j0 < (strip + 1) * OW;
+    const size_t col = (size_t)(m.ld_ok ? j0 : 0);
+    const int tau0 = ra - NT, tau1 = rb + NT;                    // level-0 rows [tau0, tau1)
+    const int tend = rb + LV + (SPLIT_NW - 1) * LAG;              // ticks [tau0, tend) for every wave
+    const int shift = w * LAG;                                    // this wave's input row = tau - shift
+    const int t0 = w * LV;                                        // level of the input rows
+    // hand-off buffers: [hand-off h][parity][field][lane]
+    auto buf = [&](int h, int parity, int field) { return lds + ((h * 2 + parity) * 3 + field) * 64 + lane; };
+
+    Row slot[S];
+#pragma unroll
+    for (int k = 0; k < S; ++k)
+#pragma unroll
+        for (int v = 0; v < V; ++v) slot[k].e.v[v] = slot[k].x.v[v] = slot[k].y.v[v] = T(0);
+
+    auto load_global = [&](Row &r, int i) {
+        const int ic = min(i, tau1 - 1);
+        const size_t o = at(g, ic, 0) + col;
+        r.e = ldn<V>(p.ez_in + o);
+        r.x = ldn<V>(p.hx_in + o);
+        r.y = ldn<V>(p.hy_in + o);
+        if (GENERAL) {
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                r.e.v[v] = m.ld_ok ? r.e.v[v] : T(0);
+                r.x.v[v] = m.ld_ok ? r.x.v[v] : T(0);
+                r.y.v[v] = m.ld_ok ? r.y.v[v] : T(0);
+            }
+        }
+    };
+    if (ROLE == 0) {
+#pragma unroll
+        for (int k = 0; k < PF; ++k) load_global(slot[k], tau0 + k);
+    }
+
+    for (int tb = tau0; tb < tend; tb += S) {
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+            const int tau = tb + k;
+            if (tau >= tend) break;                 // same trip count in every wave of the workgroup
+            const int r = tau - shift;              // input row of this wave, level t0; lives in slot k
+            if (ROLE == 0) {
+                load_global(slot[(k + PF) % S], r + PF);
+            } else {                                // row handed over by wave w-1 in the previous tick
+                const int par = (tau + 1) & 1;
+                slot[k].e = *buf(w - 1, par, 0);
+                slot[k].x = *buf(w - 1, par, 1);
+                slot[k].y = *buf(w - 1, par, 2);
+            }
+#pragma unroll
+            for (int l = 1; l <= LV; ++l) {
+                const int t = t0 + l, i = r - l;
+                if (i < ra - (NT - t) - 1 || i >= rb + (NT - t)) continue;      // outside the cone
+                Row &c = slot[(k - l + 2 * S) % S];
+                m.level(c, slot[(k - l + 1 + 2 * S) % S].e, slot[(k - l - 1 + 2 * S) % S].x, t, i);
+            }
+            const Row &f = slot[(k - LV + 2 * S) % S];       // row r - LV, now at level t0 + LV
+            if (ROLE == 2) {
+                const int io = r - LV;
+                const bool keep = st_ok && io >= ra && io < rb;
+                const size_t o = at(g, min(max(io, ra), rb - 1), 0) + col;
+                const size_t d = (size_t)lane * V;
+                stn<V>(keep ? p.ez_out + o : p.trash + d, f.e);
+                stn<V>(keep ? p.hx_out + o : p.trash + d + 64 * V, f.x);
+                stn<V>(keep ? p.hy_out + o : p.trash + d + 128 * V, f.y);
+            } else {
+                const int par = tau & 1;
+                *buf(w, par, 0) = f.e;
+                *buf(w, par, 1) = f.x;
+                *buf(w, par, 2) = f.y;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <class T, int V = Vec<T>::N>
+__global__ __launch_bounds__(64 * SPLIT_NW) void k_bulk_split(const PassParams<T> p)
+{
+    constexpr int NT = SPLIT_NT;
+    constexpr int SW = 64 * V;
+    __shared__ VecN<T, V> lds[(SPLIT_NW - 1) * 2 * 3 * 64];
+    int b = blockIdx.x;
+    if (p.fused_zones) {
+        // (zone tiles are not fused into this launch: the host always runs k_zone beside it)
+    }
+    int strip, ra, rb;
+    if (b < 2 * p.nbands_e) {
+        const int sidx = b / p.nbands_e, band = b - sidx * p.nbands_e;
+        if (sidx == 1 && p.nstrips == 1) return;
+        strip = sidx == 0 ? 0 : p.nstrips - 1;
+        ra = p.band_lo + band * p.band_rows_e;
+        rb = min(ra + p.band_rows_e, p.band_hi);
+    } else {
+        b -= 2 * p.nbands_e;
+        const int sidx = b / p.nbands, band = b - sidx * p.nbands;
+        strip = sidx + 1;
+        ra = p.band_lo + band * p.band_rows;
+        rb = min(ra + p.band_rows, p.band_hi);
+    }
+    if (ra >= rb) return;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int x0 = strip_x0<T, NT, V>(p, strip);
+    const bool edge = x0 < 5 || x0 + SW > p.g.C - 5;
+    const bool src = p.src_row >= ra - 2 * NT && p.src_row < rb + NT && p.src_col >= x0 &&
+                     p.src_col < x0 + SW;
+    // zero the hand-off buffers: the first ticks read rows nobody has written yet
+    for (int n = threadIdx.x; n < (SPLIT_NW - 1) * 2 * 3 * 64; n += 64 * SPLIT_NW)
+#pragma unroll
+        for (int v = 0; v < V; ++v) lds[n].v[v] = T(0);
+    __syncthreads();
+    if (edge || src) {
+        if (w == 0) split_body<T, true, 0, V>(p, strip, ra, rb, w, lds);
+        else if (w == SPLIT_NW - 1) split_body<T, true, 2, V>(p, strip, ra, rb, w, lds);
+        else split_body<T, true, 1, V>(p, strip, ra, rb, w, lds);
+    } else {
+        if (w == 0) split_body<T, false, 0, V>(p, strip, ra, rb, w, lds);
+        else if (w == SPLIT_NW - 1) split_body<T, false, 2, V>(p, strip, ra, rb, w, lds);
+        else split_body<T, false, 1, V>(p, strip, ra, rb, w, lds);
+    }
+}
+
+}  // namespace fdtd

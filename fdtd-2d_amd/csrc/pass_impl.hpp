@@ -19,6 +19,27 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
     const long long bulk = 2LL * p.nbands_e + (long long)p.nbands * std::max(0, p.nstrips - 2);
     const long long zones = (long long)(p.zone_top + p.zone_bot) * p.zone_tiles;
     if (bulk + zones == 0) return 0;
+    if constexpr (NT == fdtd::SPLIT_NT && !CE_ARR && !CH_ARR) {
+        if (h->use_level_split(NT, p.band_lo, p.band_hi)) {     // 4 waves per (band, strip), 2 levels each
+            p.fused_zones = 0;
+            if (zones > 0) {
+                HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
+                HIPCHK(h, hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
+                hipLaunchKernelGGL((fdtd::k_zone<T, NT, CE_ARR, CH_ARR>), dim3((unsigned)zones),
+                                   dim3(fdtd::PASS_THREADS), 0, h->side_stream, p);
+                HIPCHK(h, hipGetLastError());
+                HIPCHK(h, hipEventRecord(h->ev_join, h->side_stream));
+            }
+            if (bulk > 0) {
+                hipLaunchKernelGGL((fdtd::k_bulk_split<T, V>), dim3((unsigned)bulk),
+                                   dim3(64 * fdtd::SPLIT_NW), 0, h->stream, p);
+                HIPCHK(h, hipGetLastError());
+            }
+            if (zones > 0) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
+            h->pass_launches++;
+            return 0;
+        }
+    }
     // Small launches: zone tiles as k_zone on the side stream (ordered behind what is already
     // on h->stream; everything later on h->stream waits for both).  Large launches: fused.
     const bool split = zones > 0 && (h->zone_split < 0 ? bulk < 1600 : h->zone_split != 0);
@@ -86,7 +107,9 @@ template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, 
         // 16 rows at 2048^2, 24 at 4096^2, 64-96 at 8192^2, 96-192 at 16384^2.  Shorter bands pay
         // too much pipeline fill, taller ones leave SIMDs without a second wave to switch to.
         const int region = std::max(0, band_hi - band_lo);
-        const int want = std::max(1, (3072 + p.nstrips - 1) / p.nstrips);
+        const bool split4 = h->use_level_split(nt, band_lo, band_hi);
+        const int slots = split4 ? 2304 : 3072;     // measured: the level-split kernel likes ~32-row bands too
+        const int want = std::max(1, (slots + p.nstrips - 1) / p.nstrips);
         br = std::min(std::max(region / want, 16), 128);
     }
     p.band_rows = std::max(br, 1);

@@ -194,6 +194,9 @@ int fdtd2d_sync(fdtd2d_t *h);
  *   FDTD2D_OPT_BAND_ROWS       rows per streaming band (0 = heuristic) */
 #define FDTD2D_OPT_MAX_PASS_STEPS 0
 #define FDTD2D_OPT_BAND_ROWS      1
+#define FDTD2D_OPT_LEVEL_SPLIT    3   /* 8-step passes over uniform materials with the level-split kernel
+                                         (4 waves per band/strip, rows handed over through LDS):
+                                         -1 below ~10 M cells (default), 0 never, 1 always */
 #define FDTD2D_OPT_ZONE_SPLIT     2   /* -1 by launch size (default), 0 zone tiles fused into the
                                          bulk launch, 1 zone tiles as their own kernel on a side stream */
 int fdtd2d_set_option(fdtd2d_t *h, int option, long long value);

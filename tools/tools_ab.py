@@ -6,7 +6,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import fdtd2d_amd as fd
 
-variants = {"fused": dict(zone_split=0), "split": dict(zone_split=1)}
+variants = {"k_bulk": dict(level_split=0), "k_bulk_split": dict(level_split=1)}
 for g in (1024, 2048, 3072, 4096, 6144, 8192, 16384):
     res = {k: [] for k in variants}
     with fd.Engine(g, g, dtype=np.float32) as e:

@@ -21,7 +21,10 @@
 
 namespace fdtd {
 
-constexpr int SPLIT_NW = 4;                    // waves per workgroup
+#ifndef SPLIT_NW_
+#define SPLIT_NW_ 4
+#endif
+constexpr int SPLIT_NW = SPLIT_NW_;            // waves per workgroup
 constexpr int SPLIT_NT = 8;                    // steps per pass
 constexpr int SPLIT_LV = SPLIT_NT / SPLIT_NW;  // levels per wave
 constexpr int SPLIT_LAG = SPLIT_LV + 1;        // tick offset between consecutive waves

@@ -61,7 +61,7 @@ struct fdtd2d {
     hipEvent_t t0 = nullptr, t1 = nullptr;
     hipStream_t side_stream = nullptr;   // zone tiles run here, concurrently with the bulk
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    void *trash = nullptr;       // 4 KiB: destination of masked-off stores in k_bulk
+    void *trash = nullptr;       // destination of masked-off stores (one 4 KiB slot per workgroup index mod 1024)
     void *scratch = nullptr;     // device scratch for snapshots / reduction partials
     size_t scratch_bytes = 0;
     std::string err;

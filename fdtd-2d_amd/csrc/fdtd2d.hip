@@ -420,7 +420,7 @@ int create_impl(fdtd2d_t **out, int rows, int cols, int row0, int nrows, int hal
         if (hipMalloc(p, h->field_bytes + 256) != hipSuccess)
             return bail(fail(h, FDTD2D_E_NOMEM, "hipMalloc of %zu bytes failed", h->field_bytes));
     }
-    if (hipMalloc(&h->trash, 4096) != hipSuccess)
+    if (hipMalloc(&h->trash, fdtd::TRASH_SLOTS * fdtd::TRASH_SLOT_BYTES) != hipSuccess)
         return bail(fail(h, FDTD2D_E_NOMEM, "hipMalloc of the scratch line failed"));
     if (boundary == FDTD2D_BOUNDARY_PML) {
         const size_t fb = (size_t)(h->rows + h->cols) * 4 * h->esz;

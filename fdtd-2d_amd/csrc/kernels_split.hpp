@@ -190,7 +190,7 @@ __device__ __forceinline__ void split_body(const PassParams<T> &p, const int str
                 const int io = r - LV;
                 const bool keep = st_ok && io >= ra && io < rb;
                 const size_t o = at(g, min(max(io, ra), rb - 1), 0) + col;
-                const size_t d = (size_t)lane * V;
+                const size_t d = (size_t)(blockIdx.x % TRASH_SLOTS) * (TRASH_SLOT_BYTES / sizeof(T)) + (size_t)lane * V;
                 stn<V>(keep ? p.ez_out + o : p.trash + d, f.e);
                 stn<V>(keep ? p.hx_out + o : p.trash + d + 64 * V, f.x);
                 stn<V>(keep ? p.hy_out + o : p.trash + d + 128 * V, f.y);

@@ -34,6 +34,10 @@
 namespace fdtd {
 
 constexpr int PASS_THREADS = 256;    // threads per zone tile (4 waves share the tile through LDS)
+// Masked-off stores (pipeline fill, overlap lanes) go to a scratch area instead of being
+// branched around.  One 4 KiB slot per workgroup (index mod 1024): a single shared line would
+// be written by every CU at once.
+constexpr int TRASH_SLOTS = 1024, TRASH_SLOT_BYTES = 4096;
 constexpr int STREAM_MAX_NT = 12;   // longest pass (register budget: (NT + 4) slots x 12 VGPRs)
 // halo columns per strip side: >= NT (validity shrinks one column per level from a strip
 // edge) and a multiple of 4 so that every lane's 16-byte access stays aligned
@@ -279,7 +283,7 @@ __device__ __forceinline__ void stream_body(const PassParams<T> &p, const int st
                 const SlotT &f = slot[(k - NT + 2 * S) % S];
                 const bool keep = st_ok && io >= ra;           // else: pipeline fill / overlap lanes
                 const size_t o = at(g, max(io, ra), 0) + col;
-                const size_t d = (size_t)lane * V;
+                const size_t d = (size_t)(blockIdx.x % TRASH_SLOTS) * (TRASH_SLOT_BYTES / sizeof(T)) + (size_t)lane * V;
                 stn<V>(keep ? p.ez_out + o : p.trash + d, f.e);
                 stn<V>(keep ? p.hx_out + o : p.trash + d + 64 * V, f.x);
                 stn<V>(keep ? p.hy_out + o : p.trash + d + 128 * V, f.y);

@@ -412,3 +412,28 @@ def test_randomised_geometries_float64(fd, onp):
         for a, b, k in zip(got, ref, ("Ez", "Hx", "Hy")):
             assert np.array_equal(a, b), (f"case {case}: {k} r={r} c={c} n={n} max_nt={max_nt} band={band} "
                                           f"{kind} src=({sr},{sc}) first diff {np.argwhere(a != b)[:3]}")
+
+
+@pytest.mark.parametrize("tag,dtype", DTYPES)
+@pytest.mark.parametrize("level_split", [0, 1])
+@pytest.mark.parametrize("zone_split", [0, 1])
+@pytest.mark.parametrize("arrays", ["uniform", "eps"])
+def test_every_kernel_variant_matches_oracle(fd, onp, tag, dtype, level_split, zone_split, arrays):
+    """The engine picks k_bulk / k_bulk_split and fused / side-stream zone tiles by launch size;
+    here every combination is forced on one grid (several strips and bands, ragged width, source
+    next to a strip seam) and must give the oracle's fields exactly."""
+    r, c, n = 150, 500, 19
+    rng = np.random.default_rng(31)
+    Ez, Hx, Hy, eps, mu = _random_state(rng, r, c, dtype, onp)
+    if arrays == "uniform":
+        eps = np.full((r, c), 1.3 * onp.EPS0).astype(dtype)
+    amps = rng.standard_normal(n)
+    ref = [a.copy() for a in (Ez, Hx, Hy)]
+    onp.leapfrog(*ref, eps, mu, DT, DX, n, 77, 241, amps=amps)
+    with fd.Engine(r, c, DT, DX, dtype=dtype) as eng:
+        eng.set_materials(eps, mu).set_option(level_split=level_split, zone_split=zone_split, band_rows=20)
+        eng.upload(Ez, Hx, Hy)
+        eng.run(n, 77, 241, amps)
+        got = eng.download()
+    for a, b, k in zip(got, ref, ("Ez", "Hx", "Hy")):
+        assert np.array_equal(a, b), f"{k} level_split={level_split} zone_split={zone_split} {arrays} {tag}"

@@ -191,14 +191,22 @@ __device__ __forceinline__ void pml_body(const PassParams<T> &p, const PmlPass<T
         for (int v = 0; v < V; ++v)
             slot[k].e.v[v] = slot[k].x.v[v] = slot[k].y.v[v] = slot[k].ex.v[v] = slot[k].ce.v[v] = T(0);
 
+    // unconditional memory operations, as in stream_body: rows clamped into what exists (rows
+    // outside the grid or the band are never processed), lanes outside the grid zeroed
+    const int row_lo = max(tau0, max(0, g.row_base)), row_hi = min(tau1, g.R) - 1;
     auto load_row = [&](PmlSlot<T, CE_ARR> &r, int i) {
-        if (ld_ok && i < tau1 && i >= 0 && i < g.R) {
-            const size_t o = at(g, i, 0) + col;
-            r.e = ldv(p.ez_in + o);
-            r.x = ldv(p.hx_in + o);
-            r.y = ldv(p.hy_in + o);
-            r.ex = ldv(q.ezx_in + o);
-            if (CE_ARR) r.ce = ldv(p.ce + o);
+        const size_t o = at(g, min(max(i, row_lo), row_hi), 0) + col;
+        r.e = ldv(p.ez_in + o);
+        r.x = ldv(p.hx_in + o);
+        r.y = ldv(p.hy_in + o);
+        r.ex = ldv(q.ezx_in + o);
+        if (CE_ARR) r.ce = ldv(p.ce + o);
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            r.e.v[v] = ld_ok ? r.e.v[v] : T(0);
+            r.x.v[v] = ld_ok ? r.x.v[v] : T(0);
+            r.y.v[v] = ld_ok ? r.y.v[v] : T(0);
+            r.ex.v[v] = ld_ok ? r.ex.v[v] : T(0);
         }
     };
 #pragma unroll
@@ -254,14 +262,16 @@ __device__ __forceinline__ void pml_body(const PassParams<T> &p, const PmlPass<T
                         if (j0 + v == p.src_col) c.e.v[v] = (T)((double)c.e.v[v] + p.amp[t - 1]);
                 }
             }
-            const int io = tau - NT;
-            if (io >= ra && st_ok) {
+            {
+                const int io = tau - NT;
                 const PmlSlot<T, CE_ARR> &o_ = slot[(k - NT + 2 * S) % S];
-                const size_t o = at(g, io, 0) + col;
-                stv(p.ez_out + o, o_.e);
-                stv(p.hx_out + o, o_.x);
-                stv(p.hy_out + o, o_.y);
-                stv(q.ezx_out + o, o_.ex);
+                const bool keep = st_ok && io >= ra;
+                const size_t o = at(g, max(io, ra), 0) + col;
+                const size_t d = (size_t)(blockIdx.x % TRASH_SLOTS) * (TRASH_SLOT_BYTES / sizeof(T)) + (size_t)lane * V;
+                stv(keep ? p.ez_out + o : p.trash + d, o_.e);
+                stv(keep ? p.hx_out + o : p.trash + d + 64 * V, o_.x);
+                stv(keep ? p.hy_out + o : p.trash + d + 128 * V, o_.y);
+                stv(keep ? q.ezx_out + o : p.trash + d + 192 * V, o_.ex);
             }
         }
     }

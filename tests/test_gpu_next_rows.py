@@ -92,3 +92,18 @@ def test_time_launches_and_counters():
         eng.timer_start()
         eng.run(16)
         assert 0 < eng.timer_stop() < 100
+
+
+def test_reference_experiment_script(tmp_path, golden_dir):
+    """`python -m fdtd2d_amd.fdtd` with the reference's fdtd.py defaults scaled down: frames
+    at the reference's cadence, final field equal to the oracle's loop."""
+    from fdtd2d_amd import fdtd as script
+    from oracle import fdtd_numpy as onp
+    frames = os.path.join(str(tmp_path), "frames")
+    Ez, Hx, Hy = script.main(["--rows", "64", "--cols", "72", "--nsteps", "40", "--nframes", "8",
+                              "--frames", frames])
+    assert sorted(os.listdir(frames)) == [f"frame_{k:04d}.png" for k in range(8)]
+    ref = onp.grid_zeros(64, 72)
+    eps, mu = onp.vacuum_materials(64, 72)
+    onp.leapfrog(*ref, eps, mu, DT, DX, 40, 32, 36)
+    assert np.array_equal(Ez, ref[0]) and np.array_equal(Hx, ref[1])

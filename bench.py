@@ -20,13 +20,14 @@ Workloads (all synthetic: zero fields, ricker source at the grid centre, fp32):
 Timing: inputs resident in HBM; W untimed warm-up steps; barrier + device sync; K steps;
 device sync + barrier; max over ranks.  value = cells * K / time.
 
-roofline: the dominant kernel is k_bulk (one launch = 8 time steps over the whole slab).
+roofline: the dominant kernel is the temporally blocked pass (k_bulk_split: one launch = 16
+time steps over the whole slab for float32 + uniform materials; k_bulk: 8 steps otherwise).
 achieved = algorithmic bytes per launch / average launch duration, where algorithmic bytes
-= cells * 8 steps * (24 B + 4 B per non-uniform coefficient array)
+= cells * steps per launch * (24 B + 4 B per non-uniform coefficient array)
 and the duration is the trimmed mean of 48 back-to-back launches, each between its own pair
 of HIP events on the engine's stream (rocprofv3's per-kernel average agrees: profiles/r01f_*.txt);
-the per-launch share of the whole timed region, gaps included, is reported beside it.  Because a pass keeps 8 time levels in
-registers, the algorithmic rate may exceed the HBM peak: frac > 1 means the kernel moves
+the per-launch share of the whole timed region, gaps included, is reported beside it.  Because a pass keeps 8 or 16 time
+levels on chip, the algorithmic rate may exceed the HBM peak: frac > 1 means the kernel moves
 fewer bytes than a one-step-per-pass scheme has to ("traffic" holds the measured bytes).
 """
 import argparse
@@ -125,12 +126,13 @@ def time_single(fd, rows, cols, steps, warmup, materials, device, boundary="mur"
     eng.sync()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
+    cyc = eng.cycle_steps if boundary == "mur" else min(8, eng.cycle_steps)
     res = dict(wall_s=wall, event_ms=ev_ms, pass_launches=eng.info(16) - l0[0],
-               step_launches=eng.info(17) - l0[1], bpc=eng.bytes_per_cell_step)
-    # duration of the dominant kernel by itself: single 8-step launches, each between its own
-    # pair of HIP events on the engine's stream (what rocprofv3's kernel trace reports)
-    if res["pass_launches"] and steps >= 8:
-        one = np.sort(eng.time_launches(48, 8))
+               step_launches=eng.info(17) - l0[1], bpc=eng.bytes_per_cell_step, launch_steps=cyc)
+    # duration of the dominant kernel by itself: single full-length launches, each between its
+    # own pair of HIP events on the engine's stream (what rocprofv3's kernel trace reports)
+    if res["pass_launches"] and cyc and steps >= cyc:
+        one = np.sort(eng.time_launches(48, cyc))
         res["launch_ms"] = float(np.mean(one[4:-4]))       # trimmed mean of back-to-back launches
     Ez, _, _ = eng.download()
     assert np.isfinite(Ez).all() and np.abs(Ez).max() > 0, "benchmark produced an empty field"
@@ -154,18 +156,21 @@ def measured_traffic(rows, cols, materials, steps_per_launch):
 def roofline_block(cells, steps, r):
     """Per-launch algorithmic rate of the dominant kernel."""
     if r["pass_launches"]:
-        launches, name = r["pass_launches"], "k_bulk (temporally blocked, up to 8 steps per launch)"
+        launches = r["pass_launches"]
+        name = ("k_bulk_split (temporally blocked, 16 steps per launch)" if r.get("launch_steps") == 16
+                else "k_bulk (temporally blocked, up to 8 steps per launch)")
     else:
         launches, name = max(1, r["step_launches"] // 2), "k_update_h + k_update_e (one step)"
     region_ms = r["event_ms"] / launches                 # includes the gaps between launches
-    if "launch_ms" in r:                                   # an 8-step launch timed by itself
-        ms, bytes_per_launch = r["launch_ms"], cells * 8 * r["bpc"]
+    if "launch_ms" in r:                                   # a full-length launch timed by itself
+        ms, bytes_per_launch = r["launch_ms"], cells * r["launch_steps"] * r["bpc"]
     else:
         ms, bytes_per_launch = region_ms, cells * steps * r["bpc"] / launches
     ach = bytes_per_launch / (ms * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "kernel": name,
             "bytes_per_cell_step": r["bpc"], "launches": launches,
+            "steps_per_launch": r.get("launch_steps") if "launch_ms" in r else round(steps / launches, 3),
             "avg_launch_ms": round(ms, 5), "avg_launch_ms_incl_gaps": round(region_ms, 5),
             "algorithmic_bytes_per_launch": int(bytes_per_launch)}
 
@@ -217,7 +222,7 @@ def main():
         }
         rl = res["roofline"]
         if args.boundary == "mur" and r["pass_launches"]:
-            rl["traffic"] = measured_traffic(rows, cols, args.materials, 8)
+            rl["traffic"] = measured_traffic(rows, cols, args.materials, r["launch_steps"])
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(rows)
         print(json.dumps(res))
@@ -246,7 +251,7 @@ def main():
     exchange_mode = "overlapped"
     runner = make_runner(True)
     try:
-        runner.run(max(args.warmup, 16), sr, sc, amplitudes(fd, 0, max(args.warmup, 16)))
+        runner.run(max(args.warmup, 32), sr, sc, amplitudes(fd, 0, max(args.warmup, 32)))
         torch.cuda.synchronize()
     except Exception as exc:      # deterministic on every rank: fall back to the plain cycle
         print(f"[rank {rank}] overlapped exchange failed ({exc!r}); using the plain exchange cycle",
@@ -254,8 +259,9 @@ def main():
         exchange_mode = "plain"
         runner.close()
         runner = make_runner(False)
-        runner.run(max(args.warmup, 16), sr, sc, amplitudes(fd, 0, max(args.warmup, 16)))
+        runner.run(max(args.warmup, 32), sr, sc, amplitudes(fd, 0, max(args.warmup, 32)))
     amps = amplitudes(fd, args.warmup, args.steps)
+    cycle = min(runner.halo, runner.engine.cycle_steps or runner.halo)   # steps per exchange
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
@@ -282,8 +288,8 @@ def main():
             "ms_per_step": round(wall * 1e3 / args.steps, 5), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{rows}x{cols} fp32 TE-mode, {args.materials} eps/mu, {args.boundary} "
-                                   f"boundary, {world} row slabs of {slab} rows, halo 8 rows of "
-                                   f"Ez/Hx/Hy every 8 steps over {backend} send/recv",
+                                   f"boundary, {world} row slabs of {slab} rows, halo {cycle} rows of "
+                                   f"Ez/Hx/Hy every {cycle} steps over {backend} send/recv",
                        "grid": [rows, cols], "materials": args.materials,
                        "per_gpu_slab": [slab, cols], "fields_finite": bool(ok),
                        "exchange": exchange_mode},

@@ -80,13 +80,26 @@ struct fdtd2d {
                                  // below ~10 M cells (measured faster there), 0 never, 1 always
     bool use_level_split(int nt, int band_lo, int band_hi) const
     {
-        if (nt != 8 || !ce_uniform || !ch_uniform || boundary != FDTD2D_BOUNDARY_MUR5) return false;
+        if ((nt != 8 && nt != 16) || !ce_uniform || !ch_uniform || boundary != FDTD2D_BOUNDARY_MUR5) return false;
+        if (nt == 16) return dtype == FDTD2D_F32;      // 16-step passes exist in this form only
         if (level_split >= 0) return level_split != 0;
         return (long long)std::max(0, band_hi - band_lo) * cols < 10000000LL;
     }
+    bool max_nt_forced = false;  // set_option(MAX_PASS_STEPS): no size rule for 16-step passes
+    int cycle_steps() const      // longest pass this configuration runs
+    {
+        // 16-step passes (k_bulk_split<16>) halve the HBM traffic per step but have twice the
+        // fill/drain latency: measured faster from 4096^2 up, slower up to 3072^2
+        // (profiles/r01_nt16_sweep.txt)
+        const bool big = (size_t)nrows * cols >= (size_t)12 << 20;
+        if (max_nt >= 16 && (big || max_nt_forced) && dtype == FDTD2D_F32 && have_mat && ce_uniform &&
+            ch_uniform && boundary == FDTD2D_BOUNDARY_MUR5)
+            return 16;
+        return std::min(max_nt, 8);
+    }
     int zone_split = -1;         // -1: by launch size; 0/1: force fused / side-stream zones (FDTD2D_ZONE_SPLIT)
     int edge_band_div = 1;       // edge strips use band_rows / this (FDTD2D_EDGE_DIV; measured: no gain)
-    int max_nt = 8;              // longest pass; FDTD2D_MAX_NT / set_option override (0: step kernels only)
+    int max_nt = 16;             // longest pass; FDTD2D_MAX_NT / set_option override (0: step kernels only)
 };
 
 

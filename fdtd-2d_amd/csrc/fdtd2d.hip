@@ -429,7 +429,7 @@ int create_impl(fdtd2d_t **out, int rows, int cols, int row0, int nrows, int hal
             return bail(fail(h, FDTD2D_E_NOMEM, "hipMalloc of the PML arrays failed"));
     }
     if (const char *e2 = std::getenv("FDTD2D_BAND_ROWS")) h->stream_band_rows = std::atoi(e2);
-    if (const char *e2 = std::getenv("FDTD2D_MAX_NT")) h->max_nt = std::atoi(e2);
+    if (const char *e2 = std::getenv("FDTD2D_MAX_NT")) { h->max_nt = std::atoi(e2); h->max_nt_forced = true; }
     if (const char *e2 = std::getenv("FDTD2D_EDGE_DIV")) h->edge_band_div = std::max(1, std::atoi(e2));
     if (const char *e2 = std::getenv("FDTD2D_ZONE_SPLIT")) h->zone_split = std::atoi(e2);
     if (const char *e2 = std::getenv("FDTD2D_LEVEL_SPLIT")) h->level_split = std::atoi(e2);
@@ -587,6 +587,7 @@ long long fdtd2d_info(const fdtd2d_t *h, int what)
     case FDTD2D_INFO_STEP: return h->step;
     case FDTD2D_INFO_PASS_LAUNCHES: return h->pass_launches;
     case FDTD2D_INFO_STEP_LAUNCHES: return h->step_launches;
+    case FDTD2D_INFO_CYCLE_STEPS: return h->cycle_steps();
     default: return FDTD2D_E_ARG;
     }
 }
@@ -759,8 +760,8 @@ int fdtd2d_run(fdtd2d_t *h, int nsteps, int src_row, int src_col, const double *
     while (n < nsteps) {
         // longest temporally blocked pass that fits, else one plain step
         int nt = 0, lo = 0, hi = 0;
-        for (int c : {12, 8, 4, 2, 1})
-            if (c <= nsteps - n &&
+        for (int c : {16, 12, 8, 4, 2, 1})
+            if (c <= nsteps - n && (c != 12 || h->max_nt == 12) && (c != 16 || h->cycle_steps() == 16) &&
                 (c <= 8 || (h->dtype == FDTD2D_F32 && h->ce_uniform && h->ch_uniform)) &&
                 pass_geometry(h, c, &lo, &hi)) {
                 nt = c;
@@ -791,7 +792,10 @@ int fdtd2d_pass_rows(fdtd2d_t *h, int nt, int row_lo, int row_hi, int src_row, i
     if (h->pend_nt && h->pend_nt != nt)
         return fail(h, FDTD2D_E_STATE, "a %d-step pass is pending; cannot add rows of a %d-step pass",
                     h->pend_nt, nt);
-    if (nt != 1 && nt != 2 && nt != 4 && nt != 8) return fail(h, FDTD2D_E_ARG, "pass length must be 1, 2, 4 or 8");
+    if (nt != 1 && nt != 2 && nt != 4 && nt != 8 && nt != 16)
+        return fail(h, FDTD2D_E_ARG, "pass length must be 1, 2, 4, 8 or 16");
+    if (nt == 16 && h->cycle_steps() != 16)
+        return fail(h, FDTD2D_E_STATE, "16-step passes need float32, uniform materials and the Mur frame");
     int lo = 0, hi = 0;
     if (!pass_geometry(h, nt, &lo, &hi))
         return fail(h, FDTD2D_E_STATE, "a %d-step pass is not possible from the current state "
@@ -827,21 +831,25 @@ int fdtd2d_pass_commit(fdtd2d_t *h)
     int lo = 0, hi = 0;
     if (!pass_geometry(h, nt, &lo, &hi)) return fail(h, FDTD2D_E_STATE, "state changed under a pending pass");
     const int p_lo = h->top() ? 0 : lo, p_hi = h->bottom() ? h->rows : hi;
-    // the pieces must tile [p_lo, p_hi)
+    // the pieces must cover the owned rows without a gap; rows of [p_lo, p_hi) outside the
+    // pieces (halo rows a full pass would also have advanced) simply stop being current
     std::sort(h->pend_done.begin(), h->pend_done.end(), [](const Range &a, const Range &b) { return a.lo < b.lo; });
-    int at = p_lo;
+    const int own_lo = h->row0, own_hi = h->row0 + h->nrows;
+    int c_lo = h->pend_done.empty() ? p_hi : std::max(p_lo, h->pend_done.front().lo), at = c_lo;
     for (const Range &r : h->pend_done) {
         if (r.lo > at) break;
         at = std::max(at, r.hi);
     }
-    if (at < p_hi) {
+    at = std::min(at, p_hi);
+    if (c_lo > own_lo || at < own_hi) {
         h->pend_nt = 0;
         h->pend_done.clear();
-        return fail(h, FDTD2D_E_STATE, "pending pass covers rows up to %d of [%d,%d): dropped", at, p_lo, p_hi);
+        return fail(h, FDTD2D_E_STATE, "pending pass covers rows [%d,%d) of the owned [%d,%d): dropped",
+                    c_lo, at, own_lo, own_hi);
     }
     h->cur ^= 1;
     h->hcur ^= 1;
-    h->ev = h->hv = Range{p_lo, p_hi};
+    h->ev = h->hv = Range{c_lo, at};
     h->step += nt;
     h->pend_nt = 0;
     h->pend_done.clear();
@@ -882,8 +890,9 @@ int fdtd2d_set_option(fdtd2d_t *h, int option, long long value)
     if (!h) return FDTD2D_E_ARG;
     switch (option) {
     case FDTD2D_OPT_MAX_PASS_STEPS:
-        if (value < 0 || value > fdtd::STREAM_MAX_NT) return fail(h, FDTD2D_E_ARG, "pass length must be 0..12");
+        if (value < 0 || value > fdtd::STREAM_MAX_NT) return fail(h, FDTD2D_E_ARG, "pass length must be 0..16");
         h->max_nt = (int)value;
+        h->max_nt_forced = true;
         return 0;
     case FDTD2D_OPT_BAND_ROWS:
         if (value < 0) return fail(h, FDTD2D_E_ARG, "band rows must be >= 0");

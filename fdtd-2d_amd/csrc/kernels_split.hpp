@@ -25,9 +25,7 @@ namespace fdtd {
 #define SPLIT_NW_ 4
 #endif
 constexpr int SPLIT_NW = SPLIT_NW_;            // waves per workgroup
-constexpr int SPLIT_NT = 8;                    // steps per pass
-constexpr int SPLIT_LV = SPLIT_NT / SPLIT_NW;  // levels per wave
-constexpr int SPLIT_LAG = SPLIT_LV + 1;        // tick offset between consecutive waves
+// steps per pass NT = 8 or 16: NT / NW levels per wave, one more row of lag per hand-off
 
 // per-lane constants of a strip + the level update (same operations as stream_body)
 template <class T, bool GENERAL, int V> struct StripMath {
@@ -113,13 +111,13 @@ template <class T, bool GENERAL, int V> struct StripMath {
 };
 
 // ROLE 0: first wave (HBM -> LDS), 1: middle (LDS -> LDS), 2: last (LDS -> HBM)
-template <class T, bool GENERAL, int ROLE, int V>
+template <class T, int NT, bool GENERAL, int ROLE, int V>
 __device__ __forceinline__ void split_body(const PassParams<T> &p, const int strip, const int ra,
                                            const int rb, const int w, VecN<T, V> *lds)
 {
     using M = StripMath<T, GENERAL, V>;
     using Row = typename M::Row;
-    constexpr int NT = SPLIT_NT, LV = SPLIT_LV, LAG = SPLIT_LAG;
+    constexpr int LV = NT / SPLIT_NW, LAG = LV + 1;
     constexpr int HC = stream_hc(NT);
     constexpr int SW = 64 * V, OW = SW - 2 * HC;
     constexpr int PF = ROLE == 0 ? 2 : 0;       // only the first wave hides HBM latency
@@ -205,10 +203,10 @@ __device__ __forceinline__ void split_body(const PassParams<T> &p, const int str
     }
 }
 
-template <class T, int V = Vec<T>::N>
+template <class T, int NT, int V = Vec<T>::N>
 __global__ __launch_bounds__(64 * SPLIT_NW) void k_bulk_split(const PassParams<T> p)
 {
-    constexpr int NT = SPLIT_NT;
+    static_assert(NT % SPLIT_NW == 0, "levels must divide evenly over the waves");
     constexpr int SW = 64 * V;
     __shared__ VecN<T, V> lds[(SPLIT_NW - 1) * 2 * 3 * 64];
     int b = blockIdx.x;
@@ -241,13 +239,13 @@ __global__ __launch_bounds__(64 * SPLIT_NW) void k_bulk_split(const PassParams<T
         for (int v = 0; v < V; ++v) lds[n].v[v] = T(0);
     __syncthreads();
     if (edge || src) {
-        if (w == 0) split_body<T, true, 0, V>(p, strip, ra, rb, w, lds);
-        else if (w == SPLIT_NW - 1) split_body<T, true, 2, V>(p, strip, ra, rb, w, lds);
-        else split_body<T, true, 1, V>(p, strip, ra, rb, w, lds);
+        if (w == 0) split_body<T, NT, true, 0, V>(p, strip, ra, rb, w, lds);
+        else if (w == SPLIT_NW - 1) split_body<T, NT, true, 2, V>(p, strip, ra, rb, w, lds);
+        else split_body<T, NT, true, 1, V>(p, strip, ra, rb, w, lds);
     } else {
-        if (w == 0) split_body<T, false, 0, V>(p, strip, ra, rb, w, lds);
-        else if (w == SPLIT_NW - 1) split_body<T, false, 2, V>(p, strip, ra, rb, w, lds);
-        else split_body<T, false, 1, V>(p, strip, ra, rb, w, lds);
+        if (w == 0) split_body<T, NT, false, 0, V>(p, strip, ra, rb, w, lds);
+        else if (w == SPLIT_NW - 1) split_body<T, NT, false, 2, V>(p, strip, ra, rb, w, lds);
+        else split_body<T, NT, false, 1, V>(p, strip, ra, rb, w, lds);
     }
 }
 

@@ -38,10 +38,10 @@ constexpr int PASS_THREADS = 256;    // threads per zone tile (4 waves share the
 // branched around.  One 4 KiB slot per workgroup (index mod 1024): a single shared line would
 // be written by every CU at once.
 constexpr int TRASH_SLOTS = 1024, TRASH_SLOT_BYTES = 4096;
-constexpr int STREAM_MAX_NT = 12;   // longest pass (register budget: (NT + 4) slots x 12 VGPRs)
+constexpr int STREAM_MAX_NT = 16;   // longest pass: 8 (12) levels in one wave, 16 with the level-split kernel
 // halo columns per strip side: >= NT (validity shrinks one column per level from a strip
 // edge) and a multiple of 4 so that every lane's 16-byte access stays aligned
-constexpr int stream_hc(int nt) { return nt <= 4 ? 4 : (nt <= 8 ? 8 : 12); }
+constexpr int stream_hc(int nt) { return nt <= 4 ? 4 : (nt <= 8 ? 8 : (nt <= 12 ? 12 : 16)); }
 
 template <class T> struct PassParams {
     const T *ez_in, *hx_in, *hy_in;
@@ -298,7 +298,7 @@ template <int NT> struct ZoneDims {
     static constexpr int ZO = 5 + NT;          // rows written per zone
     static constexpr int ZR = ZO + NT + 1;     // rows held in LDS
     static constexpr int M = NT + 1;           // margin columns per side
-    static constexpr int WL = 32;              // columns held in LDS
+    static constexpr int WL = NT <= 8 ? 32 : 64;   // columns held in LDS (a power of two >= 2 M + 8)
     static constexpr int WZ = WL - 2 * M;      // columns written per tile
     static constexpr int WLP = WL + 1;         // padded LDS row
 };
@@ -320,14 +320,14 @@ template <class T, int NT, bool CE_ARR, bool CH_ARR, int THREADS>
 __device__ __forceinline__ void zone_body(const PassParams<T> &p, const int tile, const bool bottom)
 {
     using D = ZoneDims<NT>;
-    static_assert(D::WL == 32, "lane -> column mapping below assumes 32-column tiles");
+    static_assert((D::WL & (D::WL - 1)) == 0 && THREADS % D::WL == 0 && D::WZ >= 8, "tile shape");
     __shared__ T sE[2][D::ZR * D::WLP];
     __shared__ T sX[D::ZR * D::WLP];
     __shared__ T sY[D::ZR * D::WLP];
     const Geom g = p.g;
-    // thread -> (row group, column): THREADS/32 tile rows per sweep, no integer division
-    constexpr int RG = THREADS / 32;
-    const int lj = threadIdx.x & 31, lr = threadIdx.x >> 5;
+    // thread -> (row group, column): THREADS/WL tile rows per sweep, no integer division
+    constexpr int RG = THREADS / D::WL;
+    const int lj = threadIdx.x & (D::WL - 1), lr = threadIdx.x / D::WL;
     // rows held [z0, z0+ZR), rows written [o0, o0+ZO)
     const int z0 = bottom ? g.R - D::ZR : 0;
     const int o0 = bottom ? g.R - D::ZO : 0;

@@ -19,7 +19,7 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
     const long long bulk = 2LL * p.nbands_e + (long long)p.nbands * std::max(0, p.nstrips - 2);
     const long long zones = (long long)(p.zone_top + p.zone_bot) * p.zone_tiles;
     if (bulk + zones == 0) return 0;
-    if constexpr (NT == fdtd::SPLIT_NT && !CE_ARR && !CH_ARR) {
+    if constexpr ((NT == 8 || NT == 16) && !CE_ARR && !CH_ARR) {
         if (h->use_level_split(NT, p.band_lo, p.band_hi)) {     // 4 waves per (band, strip), 2 levels each
             p.fused_zones = 0;
             if (zones > 0) {
@@ -31,7 +31,7 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
                 HIPCHK(h, hipEventRecord(h->ev_join, h->side_stream));
             }
             if (bulk > 0) {
-                hipLaunchKernelGGL((fdtd::k_bulk_split<T, V>), dim3((unsigned)bulk),
+                hipLaunchKernelGGL((fdtd::k_bulk_split<T, NT, V>), dim3((unsigned)bulk),
                                    dim3(64 * fdtd::SPLIT_NW), 0, h->stream, p);
                 HIPCHK(h, hipGetLastError());
             }
@@ -40,6 +40,9 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
             return 0;
         }
     }
+    if constexpr (NT > 12) {
+        return fail(h, FDTD2D_E_ARG, "16-step passes need float32 and uniform materials");
+    } else {
     // Small launches: zone tiles as k_zone on the side stream (ordered behind what is already
     // on h->stream; everything later on h->stream waits for both).  Large launches: fused.
     const bool split = zones > 0 && (h->zone_split < 0 ? bulk < 1600 : h->zone_split != 0);
@@ -61,6 +64,7 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
     if (split) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
     h->pass_launches++;
     return 0;
+    }
 }
 
 template <class T, int NT> int launch_pass_nt(fdtd2d *h, fdtd::PassParams<T> &p)
@@ -110,7 +114,8 @@ template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, 
         const bool split4 = h->use_level_split(nt, band_lo, band_hi);
         const int slots = split4 ? 2304 : 3072;     // measured: the level-split kernel likes ~32-row bands too
         const int want = std::max(1, (slots + p.nstrips - 1) / p.nstrips);
-        br = std::min(std::max(region / want, 16), 128);
+        br = nt > 12 ? std::min(std::max(region / want, 64), 512)       // 35 ticks of fill per band
+                     : std::min(std::max(region / want, 16), 128);
     }
     p.band_rows = std::max(br, 1);
     p.zone_top = ztop;
@@ -150,6 +155,9 @@ template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, 
         rc = 0;
     } else
     switch (nt) {
+    case 16:
+        if constexpr (sizeof(T) == 4) { rc = launch_pass_nt<T, 16>(h, p); break; }
+        return fail(h, FDTD2D_E_ARG, "16-step passes are built for float32 only");
     case 12:
         if constexpr (sizeof(T) == 4) { rc = launch_pass_nt<T, 12>(h, p); break; }
         return fail(h, FDTD2D_E_ARG, "12-step passes are built for float32 only");

@@ -321,5 +321,10 @@ class Engine:
         return np.array(out[:], dtype=np.float64)
 
     @property
+    def cycle_steps(self) -> int:
+        """Longest temporally blocked pass the current configuration runs (16 / 8 / 0)."""
+        return self.info(_abi.INFO_CYCLE_STEPS)
+
+    @property
     def step_count(self) -> int:
         return self.info(_abi.INFO_STEP)

@@ -26,7 +26,8 @@ from __future__ import annotations
 
 import numpy as np
 
-HALO = 8   # rows per exchange = steps per exchange (the longest temporally blocked pass)
+HALO = 16  # halo rows stored and exchanged = the longest temporally blocked pass (16 steps for
+           # float32 + uniform materials; other configurations run 8 steps per exchange)
 
 
 def plan_slabs(rows: int, world: int, halo: int = HALO):
@@ -65,7 +66,7 @@ class SlabRunner:
     per-rank engine (default: the HIP Engine)."""
 
     def __init__(self, rows, cols, dt=5e-14, dx=1e-4, dtype=np.float32, boundary="mur", device=0,
-                 halo=HALO, group=None, engine_factory=None, overlap=True):
+                 halo=None, group=None, engine_factory=None, overlap=True):
         import torch
         import torch.distributed as dist
         self.dist, self.torch = dist, torch
@@ -74,6 +75,8 @@ class SlabRunner:
         self.world = dist.get_world_size(group)
         self.rows, self.cols, self.dt, self.dx = int(rows), int(cols), float(dt), float(dx)
         self.dtype = np.dtype(dtype)
+        if halo is None:     # 16 rows where the slabs are tall enough for them, else 8
+            halo = HALO if self.rows // self.world >= 6 + HALO else 8
         self.halo = int(halo) if self.world > 1 else 0
         self.plan = plan_slabs(self.rows, self.world, max(self.halo, 1))
         self.r0, self.r1 = self.plan[self.rank]
@@ -211,7 +214,7 @@ class SlabRunner:
         self._halo_fresh = True
 
     def _cycle_overlapped(self, n, src_row, src_col, amps):
-        """One pass of n = halo steps with the exchange for the NEXT pass hidden behind the
+        """One pass of n (8 or 16) steps with the exchange for the NEXT pass hidden behind the
         interior: (edge stream) rows next to the cuts -> pack -> send/recv;  (main stream)
         everything else;  then commit and unpack.  Needs fresh halos, leaves fresh halos."""
         torch, eng, sides = self.torch, self.engine, self._sides()
@@ -254,13 +257,18 @@ class SlabRunner:
         done = 0
         can_overlap = self.overlap and (self.r1 - self.r0) >= 2 * self.halo + 1 and \
             hasattr(self.engine, "pass_rows")
+        # steps per exchange: the longest pass the engine runs in this configuration (16 or 8)
+        cycle = min(self.halo, getattr(self.engine, "cycle_steps", self.halo) or self.halo)
+        # grids below 2*(2*cycle+6) rows have no temporally blocked pass (the engine advances
+        # them with its single-step kernels), hence nothing to issue in pieces
+        can_overlap = can_overlap and self.rows >= 2 * (2 * cycle + 6)
         with self._on_stream():
             while done < nsteps:
-                n = nsteps - done if self.world == 1 else min(self.halo, nsteps - done)
+                n = nsteps - done if self.world == 1 else min(cycle, nsteps - done)
                 a = None if amps is None else amps[done:done + n]
                 if self.world > 1 and not self._halo_fresh:
                     self.exchange()
-                if can_overlap and n == self.halo:
+                if can_overlap and n == cycle and n in (8, 16):
                     self._cycle_overlapped(n, src_row, src_col, a)
                 else:
                     self.engine.run(n, src_row, src_col, a)

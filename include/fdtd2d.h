@@ -79,6 +79,8 @@ typedef struct fdtd2d fdtd2d_t;
 #define FDTD2D_INFO_STEP        15 /* completed E half-steps since create/upload */
 #define FDTD2D_INFO_PASS_LAUNCHES 16 /* temporally blocked pass kernels launched so far */
 #define FDTD2D_INFO_STEP_LAUNCHES 17 /* single half-step kernels launched so far */
+#define FDTD2D_INFO_CYCLE_STEPS   18 /* longest pass the current configuration runs: 16 (float32,
+                                         uniform materials, Mur frame), else 8, 0 if passes are off */
 
 /* ---- lifetime ------------------------------------------------------------------ */
 
@@ -166,7 +168,7 @@ int fdtd2d_add_point(fdtd2d_t *h, int row, int col, double amp);
  * neighbours, nsteps must not exceed the halo validity left. */
 int fdtd2d_run(fdtd2d_t *h, int nsteps, int src_row, int src_col, const double *amps);
 
-/* One temporally blocked pass of nt in {1,2,4,8} steps issued in pieces, so that a caller can
+/* One temporally blocked pass of nt in {1,2,4,8,16} steps issued in pieces, so that a caller can
  * compute the rows its neighbours wait for first, send them, and overlap the transfer with
  * the rest: fdtd2d_pass_rows() launches the pass for output rows [row_lo,row_hi) only (reading
  * the current fields, writing the other buffer set; pieces may go to different streams via
@@ -187,10 +189,13 @@ double fdtd2d_source_amplitude(int src_kind, double t, double fc);
 int fdtd2d_sync(fdtd2d_t *h);
 
 /* Tuning knobs of fdtd2d_run (results do not depend on them, only speed):
- *   FDTD2D_OPT_MAX_PASS_STEPS  longest temporally blocked pass, 0..12 (0 = plain single steps
- *                              with the half-step kernels); default 8.  12-step passes exist
- *                              for float32 with uniform materials only (measured slower than 8
- *                              on 4096^2, about equal on 16384^2: profiles/r01_nt12_sweep.txt).
+ *   FDTD2D_OPT_MAX_PASS_STEPS  longest temporally blocked pass, 0..16 (0 = plain single steps
+ *                              with the half-step kernels); default 16.  16-step passes (level-
+ *                              split kernel) exist for float32 with uniform materials and the
+ *                              Mur frame; everything else runs 8-step passes.  By default they
+ *                              are used from 12 Mi cells per GPU up (faster from 4096^2, slower
+ *                              below: profiles/r01_nt16_sweep.txt); setting this option to 16
+ *                              explicitly uses them at every size.
  *   FDTD2D_OPT_BAND_ROWS       rows per streaming band (0 = heuristic) */
 #define FDTD2D_OPT_MAX_PASS_STEPS 0
 #define FDTD2D_OPT_BAND_ROWS      1

@@ -22,6 +22,7 @@ def worker(rank, world, port, job, outdir):
     for p in (ROOT, os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
+    os.environ["FAKE_ENGINE_CYCLE"] = str(job.get("cycle", 8))
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -42,6 +43,9 @@ def worker(rank, world, port, job, outdir):
             runner.set_materials(float(st["eps"][0, 0]), float(st["mu"][0, 0]))
         else:
             runner.set_materials(st["eps"][lo:hi].astype(dtype), st["mu"][lo:hi].astype(dtype))
+        if job.get("options"):
+            runner.engine.set_option(**job["options"])
+            assert runner.engine.cycle_steps == job["options"].get("max_pass_steps", 8)
         runner.upload(st["Ez"][r0:r1].astype(dtype), st["Hx"][r0:r1].astype(dtype),
                       st["Hy"][r0:min(r1, rows - 1)].astype(dtype))
         done = 0

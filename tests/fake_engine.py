@@ -9,6 +9,8 @@ neighbours' true values -- which is exactly what the runner is responsible for.
 """
 import ctypes
 
+import os
+
 import numpy as np
 
 from oracle import fdtd_numpy as onp
@@ -21,8 +23,10 @@ def _view(ptr, n, dtype):
 
 class FakeEngine:
     buffer_device = "cpu"
+    cycle_steps = 8          # like the HIP engine with array materials: 8 steps per exchange
 
     def __init__(self, rows, cols, dt, dx, dtype=np.float32, boundary="mur", device=0, slab=None):
+        self.cycle_steps = int(os.environ.get("FAKE_ENGINE_CYCLE", "8"))
         assert boundary == "mur"
         self.rows, self.cols, self.dt, self.dx, self.dtype = rows, cols, dt, dx, np.dtype(dtype)
         self.row0, self.nrows, self.halo = (0, rows, 0) if slab is None else slab

@@ -437,3 +437,28 @@ def test_every_kernel_variant_matches_oracle(fd, onp, tag, dtype, level_split, z
         got = eng.download()
     for a, b, k in zip(got, ref, ("Ez", "Hx", "Hy")):
         assert np.array_equal(a, b), f"{k} level_split={level_split} zone_split={zone_split} {arrays} {tag}"
+
+
+@pytest.mark.parametrize("shape", [(76, 64), (100, 225), (130, 470), (200, 1000)])
+@pytest.mark.parametrize("src", [(0, 0), (20, 30), (21, 223), (60, 100)])
+def test_16_step_passes_match_oracle(fd, onp, shape, src):
+    """16-step passes (level-split kernel, 4 levels per wave; zone tiles 21 rows deep, 64 columns
+    wide), float32 uniform materials, from a random state; 35 steps = 16 + 16 + 2 + 1."""
+    r, c = shape
+    rng = np.random.default_rng(r * c)
+    Ez, Hx, Hy, _, _ = _random_state(rng, r, c, np.float32, onp)
+    eps = np.full((r, c), 1.9 * onp.EPS0, np.float32)
+    mu = np.full((r, c), onp.MU0, np.float32)
+    n = 35
+    amps = rng.standard_normal(n)
+    sr, sc = min(src[0], r - 1), min(src[1], c - 1)
+    ref = [a.copy() for a in (Ez, Hx, Hy)]
+    onp.leapfrog(*ref, eps, mu, DT, DX, n, sr, sc, amps=amps)
+    with fd.Engine(r, c, DT, DX, dtype=np.float32) as eng:
+        eng.set_materials(eps, mu).set_option(max_pass_steps=16)
+        eng.upload(Ez, Hx, Hy)
+        eng.run(n, sr, sc, amps)
+        got = eng.download()
+        assert eng.info(16) == 4
+    for a, b, k in zip(got, ref, ("Ez", "Hx", "Hy")):
+        assert np.array_equal(a, b), f"{k} {shape} src={src}: {np.argwhere(a != b)[:4]}"

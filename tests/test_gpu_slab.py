@@ -14,18 +14,23 @@ from dist_harness import run_job
 DT, DX = 5e-14, 1e-4
 
 
-@pytest.mark.parametrize("world,shape,dtype,materials,overlap", [
-    (2, (200, 300), "float32", "array", True),
-    (3, (180, 520), "float32", "array", True),
-    (2, (128, 256), "float64", "array", True),
-    (2, (160, 700), "float32", "uniform", True),
-    (3, (180, 520), "float32", "array", False),
+@pytest.mark.parametrize("world,shape,dtype,materials,overlap,options", [
+    (2, (200, 300), "float32", "array", True, None),
+    (3, (180, 520), "float32", "array", True, None),
+    (2, (128, 256), "float64", "array", True, None),
+    (2, (160, 700), "float32", "uniform", True, None),
+    (3, (180, 520), "float32", "array", False, None),
+    (2, (40, 300), "float32", "array", True, None),                         # 8-row halo
+    (2, (160, 700), "float32", "uniform", True, {"max_pass_steps": 16}),    # 16 steps per exchange
+    (3, (300, 1100), "float32", "uniform", True, {"max_pass_steps": 16}),
+    (2, (160, 700), "float32", "uniform", False, {"max_pass_steps": 16}),
 ])
-def test_gpu_slabs_match_single_engine_and_oracle(tmp_path, world, shape, dtype, materials, overlap):
+def test_gpu_slabs_match_single_engine_and_oracle(tmp_path, world, shape, dtype, materials, overlap,
+                                                  options):
     import fdtd2d_amd as fd
     from oracle import fdtd_numpy as onp
     r, c = shape
-    n = 29                                   # 8+8+8+5 per exchange cycle -> passes 8,8,8,4,1
+    n = 45 if options else 29                # exchange cycles 8+8+8+5 (passes 8,8,8,4,1) / 16+16+13
     rng = np.random.default_rng(r + c)
     st = dict(Ez=rng.standard_normal((r, c)), Hx=rng.standard_normal((r, c - 1)) * 1e-3,
               Hy=rng.standard_normal((r - 1, c)) * 1e-3,
@@ -37,7 +42,7 @@ def test_gpu_slabs_match_single_engine_and_oracle(tmp_path, world, shape, dtype,
     np.savez(path, **st)
     src = (r // world, c // 2)               # on the first cut
     job = dict(engine="hip", shape=shape, dtype=dtype, dt=DT, dx=DX, state=path, src=src,
-               chunks=[n], materials=materials, overlap=overlap)
+               chunks=[n], materials=materials, overlap=overlap, options=options)
     got = run_job(world, job, str(tmp_path))
     dt_ = np.dtype(dtype)
     with fd.Engine(r, c, DT, DX, dtype=dt_) as eng:

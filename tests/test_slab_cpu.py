@@ -23,7 +23,7 @@ def test_plan_slabs():
     assert max(b - a for a, b in p) - min(b - a for a, b in p) <= 1
     assert plan_slabs(16384, 4) == [(0, 4096), (4096, 8192), (8192, 12288), (12288, 16384)]
     with pytest.raises(ValueError):
-        plan_slabs(40, 4)          # 10-row slabs cannot hold the 6+8 row clearance
+        plan_slabs(40, 4, halo=8)  # 10-row slabs cannot hold the 6+8 row clearance
 
 
 def _state(tmp_path, r, c, seed, nsteps, vary_mu=False):
@@ -55,6 +55,23 @@ def test_slab_runner_matches_single_domain_oracle(tmp_path, world, shape, src, d
                  amps=st["amps"])
     for a, b, k in zip(got, ref, ("Ez", "Hx", "Hy")):
         assert a.shape == b.shape and np.array_equal(a, b), k
+
+
+@pytest.mark.parametrize("cycle", [8, 16])
+@pytest.mark.parametrize("overlap", [True, False])
+def test_slab_runner_16_row_halo(tmp_path, cycle, overlap):
+    """Slabs tall enough for the 16-row halo: 16 steps per exchange where the engine runs
+    16-step passes (cycle 16), two 8-step cycles' worth of rows per message otherwise."""
+    r, c = 50, 24
+    st, path = _state(str(tmp_path), r, c, 77, 51, vary_mu=True)
+    job = dict(engine="fake", shape=(r, c), dtype="float32", dt=DT, dx=DX, state=path,
+               src=(25, 3), chunks=[35, 16], materials="array", overlap=overlap, cycle=cycle)
+    got = run_job(2, job, str(tmp_path))
+    ref = [st[k].astype(np.float32) for k in ("Ez", "Hx", "Hy")]
+    onp.leapfrog(*ref, st["eps"].astype(np.float32), st["mu"].astype(np.float32), DT, DX, 51,
+                 25, 3, amps=st["amps"])
+    for a, b, k in zip(got, ref, ("Ez", "Hx", "Hy")):
+        assert np.array_equal(a, b), k
 
 
 def test_slab_runner_uniform_materials(tmp_path):

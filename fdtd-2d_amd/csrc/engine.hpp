@@ -85,6 +85,14 @@ struct fdtd2d {
         if (level_split >= 0) return level_split != 0;
         return (long long)std::max(0, band_hi - band_lo) * cols < 10000000LL;
     }
+    int split_waves = 0;         // waves per strip in k_bulk_split: 0 = automatic, 4 or 8
+    int split_waves_for(int nt, int lo, int hi) const
+    {
+        // 16-step passes: 8 waves x 2 levels measured 10 % faster than 4 x 4 at 4096^2, equal
+        // or slower from 6144^2 up and for 8-step passes (profiles/r01_split_waves_sweep.txt)
+        if (split_waves) return split_waves;
+        return nt == 16 && (size_t)std::max(0, hi - lo) * cols < ((size_t)28 << 20) ? 8 : 4;
+    }
     bool max_nt_forced = false;  // set_option(MAX_PASS_STEPS): no size rule for 16-step passes
     int cycle_steps() const      // longest pass this configuration runs
     {

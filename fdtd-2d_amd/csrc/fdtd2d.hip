@@ -902,6 +902,10 @@ int fdtd2d_set_option(fdtd2d_t *h, int option, long long value)
         if (value < -1 || value > 1) return fail(h, FDTD2D_E_ARG, "level split must be -1, 0 or 1");
         h->level_split = (int)value;
         return 0;
+    case FDTD2D_OPT_SPLIT_WAVES:
+        if (value != 0 && value != 4 && value != 8) return fail(h, FDTD2D_E_ARG, "split waves must be 0, 4 or 8");
+        h->split_waves = (int)value;
+        return 0;
     case FDTD2D_OPT_ZONE_SPLIT:
         if (value < -1 || value > 1) return fail(h, FDTD2D_E_ARG, "zone split must be -1, 0 or 1");
         h->zone_split = (int)value;

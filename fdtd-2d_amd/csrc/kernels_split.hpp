@@ -21,11 +21,10 @@
 
 namespace fdtd {
 
-#ifndef SPLIT_NW_
-#define SPLIT_NW_ 4
-#endif
-constexpr int SPLIT_NW = SPLIT_NW_;            // waves per workgroup
-// steps per pass NT = 8 or 16: NT / NW levels per wave, one more row of lag per hand-off
+// NW waves per workgroup (4 or 8), steps per pass NT = 8 or 16: NT / NW levels per wave, one
+// more row of lag per hand-off.  More waves per strip = fewer levels per wave and tick, so the
+// same number of resident waves covers taller bands (less fill per band) -- the better trade on
+// grids that cannot fill the GPU otherwise.
 
 // per-lane constants of a strip + the level update (same operations as stream_body)
 template <class T, bool GENERAL, int V> struct StripMath {
@@ -111,7 +110,7 @@ template <class T, bool GENERAL, int V> struct StripMath {
 };
 
 // ROLE 0: first wave (HBM -> LDS), 1: middle (LDS -> LDS), 2: last (LDS -> HBM)
-template <class T, int NT, bool GENERAL, int ROLE, int V>
+template <class T, int NT, int SPLIT_NW, bool GENERAL, int ROLE, int V>
 __device__ __forceinline__ void split_body(const PassParams<T> &p, const int strip, const int ra,
                                            const int rb, const int w, VecN<T, V> *lds)
 {
@@ -203,7 +202,7 @@ __device__ __forceinline__ void split_body(const PassParams<T> &p, const int str
     }
 }
 
-template <class T, int NT, int V = Vec<T>::N>
+template <class T, int NT, int SPLIT_NW, int V = Vec<T>::N>
 __global__ __launch_bounds__(64 * SPLIT_NW) void k_bulk_split(const PassParams<T> p)
 {
     static_assert(NT % SPLIT_NW == 0, "levels must divide evenly over the waves");
@@ -239,13 +238,13 @@ __global__ __launch_bounds__(64 * SPLIT_NW) void k_bulk_split(const PassParams<T
         for (int v = 0; v < V; ++v) lds[n].v[v] = T(0);
     __syncthreads();
     if (edge || src) {
-        if (w == 0) split_body<T, NT, true, 0, V>(p, strip, ra, rb, w, lds);
-        else if (w == SPLIT_NW - 1) split_body<T, NT, true, 2, V>(p, strip, ra, rb, w, lds);
-        else split_body<T, NT, true, 1, V>(p, strip, ra, rb, w, lds);
+        if (w == 0) split_body<T, NT, SPLIT_NW, true, 0, V>(p, strip, ra, rb, w, lds);
+        else if (w == SPLIT_NW - 1) split_body<T, NT, SPLIT_NW, true, 2, V>(p, strip, ra, rb, w, lds);
+        else split_body<T, NT, SPLIT_NW, true, 1, V>(p, strip, ra, rb, w, lds);
     } else {
-        if (w == 0) split_body<T, NT, false, 0, V>(p, strip, ra, rb, w, lds);
-        else if (w == SPLIT_NW - 1) split_body<T, NT, false, 2, V>(p, strip, ra, rb, w, lds);
-        else split_body<T, NT, false, 1, V>(p, strip, ra, rb, w, lds);
+        if (w == 0) split_body<T, NT, SPLIT_NW, false, 0, V>(p, strip, ra, rb, w, lds);
+        else if (w == SPLIT_NW - 1) split_body<T, NT, SPLIT_NW, false, 2, V>(p, strip, ra, rb, w, lds);
+        else split_body<T, NT, SPLIT_NW, false, 1, V>(p, strip, ra, rb, w, lds);
     }
 }
 

@@ -31,8 +31,12 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
                 HIPCHK(h, hipEventRecord(h->ev_join, h->side_stream));
             }
             if (bulk > 0) {
-                hipLaunchKernelGGL((fdtd::k_bulk_split<T, NT, V>), dim3((unsigned)bulk),
-                                   dim3(64 * fdtd::SPLIT_NW), 0, h->stream, p);
+                if (h->split_waves_for(NT, p.band_lo, p.band_hi) == 8)
+                    hipLaunchKernelGGL((fdtd::k_bulk_split<T, NT, 8, V>), dim3((unsigned)bulk), dim3(512), 0,
+                                       h->stream, p);
+                else
+                    hipLaunchKernelGGL((fdtd::k_bulk_split<T, NT, 4, V>), dim3((unsigned)bulk), dim3(256), 0,
+                                       h->stream, p);
                 HIPCHK(h, hipGetLastError());
             }
             if (zones > 0) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
@@ -114,8 +118,18 @@ template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, 
         const bool split4 = h->use_level_split(nt, band_lo, band_hi);
         const int slots = split4 ? 2304 : 3072;     // measured: the level-split kernel likes ~32-row bands too
         const int want = std::max(1, (slots + p.nstrips - 1) / p.nstrips);
-        br = nt > 12 ? std::min(std::max(region / want, 64), 512)       // 35 ticks of fill per band
-                     : std::min(std::max(region / want, 16), 128);
+        br = nt > 12 ? std::min(std::max(region / want, 64), 512)       // ~24 ticks of fill per band
+                     : std::min(std::max(region / want, split4 ? 32 : 16), 128);
+        // Workgroups resident at once: 256 CUs x 4 (16-step, 4 waves each, 117 VGPRs) or x 5
+        // (8-step, 93 VGPRs).  A launch of 1.0-1.6 times that leaves a thin second round; one
+        // round of taller bands measured 5-10 % faster (4096^2 and 2048x8192 at 16 steps, 3072^2
+        // at 8: profiles/r01_band16_sweep.txt, r01_split_waves_sweep.txt).  With 8 waves per
+        // strip the shortest bands were fastest.
+        if (split4 && h->split_waves_for(nt, band_lo, band_hi) == 4) {
+            const int cap = nt > 12 ? 1024 : 1280, fit = std::max(1, (cap * 9 / 10) / p.nstrips);
+            const long long wgs = (long long)((region + br - 1) / br) * p.nstrips;
+            if (wgs > cap * 92 / 100 && wgs <= cap * 16 / 10) br = std::max(br, (region + fit - 1) / fit);
+        }
     }
     p.band_rows = std::max(br, 1);
     p.zone_top = ztop;

@@ -255,7 +255,8 @@ class Engine:
                                                int(src_col), float(fc), int(step0)))
         return self
 
-    def set_option(self, max_pass_steps=None, band_rows=None, zone_split=None, level_split=None):
+    def set_option(self, max_pass_steps=None, band_rows=None, zone_split=None, level_split=None,
+                   split_waves=None):
         """Speed knobs of run(): longest temporally blocked pass (0 = single-step kernels
         only) and rows per streaming band.  Results do not depend on them."""
         if max_pass_steps is not None:
@@ -266,6 +267,8 @@ class Engine:
             self._ck(self._lib.fdtd2d_set_option(self._h, _abi.OPT_ZONE_SPLIT, int(zone_split)))
         if level_split is not None:
             self._ck(self._lib.fdtd2d_set_option(self._h, _abi.OPT_LEVEL_SPLIT, int(level_split)))
+        if split_waves is not None:
+            self._ck(self._lib.fdtd2d_set_option(self._h, _abi.OPT_SPLIT_WAVES, int(split_waves)))
         return self
 
     def sync(self):

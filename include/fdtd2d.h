@@ -204,6 +204,8 @@ int fdtd2d_sync(fdtd2d_t *h);
                                          -1 below ~10 M cells (default), 0 never, 1 always */
 #define FDTD2D_OPT_ZONE_SPLIT     2   /* -1 by launch size (default), 0 zone tiles fused into the
                                          bulk launch, 1 zone tiles as their own kernel on a side stream */
+#define FDTD2D_OPT_SPLIT_WAVES    4   /* waves per band/strip in the level-split kernel: 0 automatic
+                                         (default), 4 or 8 */
 int fdtd2d_set_option(fdtd2d_t *h, int option, long long value);
 
 /* ---- row-slab halo exchange (transport is the caller's: RCCL via torch.distributed) -- */

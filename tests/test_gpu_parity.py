@@ -415,7 +415,7 @@ def test_randomised_geometries_float64(fd, onp):
 
 
 @pytest.mark.parametrize("tag,dtype", DTYPES)
-@pytest.mark.parametrize("level_split", [0, 1])
+@pytest.mark.parametrize("level_split", [0, 1, 8])
 @pytest.mark.parametrize("zone_split", [0, 1])
 @pytest.mark.parametrize("arrays", ["uniform", "eps"])
 def test_every_kernel_variant_matches_oracle(fd, onp, tag, dtype, level_split, zone_split, arrays):
@@ -431,7 +431,8 @@ def test_every_kernel_variant_matches_oracle(fd, onp, tag, dtype, level_split, z
     ref = [a.copy() for a in (Ez, Hx, Hy)]
     onp.leapfrog(*ref, eps, mu, DT, DX, n, 77, 241, amps=amps)
     with fd.Engine(r, c, DT, DX, dtype=dtype) as eng:
-        eng.set_materials(eps, mu).set_option(level_split=level_split, zone_split=zone_split, band_rows=20)
+        eng.set_materials(eps, mu).set_option(level_split=min(level_split, 1), zone_split=zone_split,
+                                              band_rows=20, split_waves=8 if level_split == 8 else 4)
         eng.upload(Ez, Hx, Hy)
         eng.run(n, 77, 241, amps)
         got = eng.download()
@@ -439,11 +440,13 @@ def test_every_kernel_variant_matches_oracle(fd, onp, tag, dtype, level_split, z
         assert np.array_equal(a, b), f"{k} level_split={level_split} zone_split={zone_split} {arrays} {tag}"
 
 
+@pytest.mark.parametrize("split_waves", [4, 8])
 @pytest.mark.parametrize("shape", [(76, 64), (100, 225), (130, 470), (200, 1000)])
 @pytest.mark.parametrize("src", [(0, 0), (20, 30), (21, 223), (60, 100)])
-def test_16_step_passes_match_oracle(fd, onp, shape, src):
-    """16-step passes (level-split kernel, 4 levels per wave; zone tiles 21 rows deep, 64 columns
-    wide), float32 uniform materials, from a random state; 35 steps = 16 + 16 + 2 + 1."""
+def test_16_step_passes_match_oracle(fd, onp, shape, src, split_waves):
+    """16-step passes (level-split kernel, 4 waves x 4 levels or 8 waves x 2 levels; zone tiles 21
+    rows deep, 64 columns wide), float32 uniform materials, from a random state; 35 steps =
+    16 + 16 + 2 + 1."""
     r, c = shape
     rng = np.random.default_rng(r * c)
     Ez, Hx, Hy, _, _ = _random_state(rng, r, c, np.float32, onp)
@@ -455,7 +458,7 @@ def test_16_step_passes_match_oracle(fd, onp, shape, src):
     ref = [a.copy() for a in (Ez, Hx, Hy)]
     onp.leapfrog(*ref, eps, mu, DT, DX, n, sr, sc, amps=amps)
     with fd.Engine(r, c, DT, DX, dtype=np.float32) as eng:
-        eng.set_materials(eps, mu).set_option(max_pass_steps=16)
+        eng.set_materials(eps, mu).set_option(max_pass_steps=16, split_waves=split_waves, band_rows=48)
         eng.upload(Ez, Hx, Hy)
         eng.run(n, sr, sc, amps)
         got = eng.download()

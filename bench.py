@@ -128,7 +128,8 @@ def time_single(fd, rows, cols, steps, warmup, materials, device, boundary="mur"
     wall = time.perf_counter() - t0
     cyc = eng.cycle_steps if boundary == "mur" else min(8, eng.cycle_steps)
     res = dict(wall_s=wall, event_ms=ev_ms, pass_launches=eng.info(16) - l0[0],
-               step_launches=eng.info(17) - l0[1], bpc=eng.bytes_per_cell_step, launch_steps=cyc)
+               step_launches=eng.info(17) - l0[1], bpc=eng.bytes_per_cell_step, launch_steps=cyc,
+               band_rows=eng.info(19), waves_per_strip=eng.info(20))
     # duration of the dominant kernel by itself: single full-length launches, each between its
     # own pair of HIP events on the engine's stream (what rocprofv3's kernel trace reports)
     if res["pass_launches"] and cyc and steps >= cyc:
@@ -171,6 +172,7 @@ def roofline_block(cells, steps, r):
             "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "kernel": name,
             "bytes_per_cell_step": r["bpc"], "launches": launches,
             "steps_per_launch": r.get("launch_steps") if "launch_ms" in r else round(steps / launches, 3),
+            "launch_shape": {"band_rows": r.get("band_rows"), "waves_per_strip": r.get("waves_per_strip")},
             "avg_launch_ms": round(ms, 5), "avg_launch_ms_incl_gaps": round(region_ms, 5),
             "algorithmic_bytes_per_launch": int(bytes_per_launch)}
 

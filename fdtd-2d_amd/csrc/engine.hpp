@@ -7,6 +7,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
+#include <map>
 #include <cstdarg>
 #include <cstdio>
 #include <string>
@@ -80,14 +82,26 @@ struct fdtd2d {
                                  // below ~10 M cells (measured faster there), 0 never, 1 always
     bool use_level_split(int nt, int band_lo, int band_hi) const
     {
-        if ((nt != 8 && nt != 16) || !ce_uniform || !ch_uniform || boundary != FDTD2D_BOUNDARY_MUR5) return false;
+        if ((nt != 8 && nt != 16) || boundary != FDTD2D_BOUNDARY_MUR5) return false;
         if (nt == 16) return dtype == FDTD2D_F32;      // 16-step passes exist in this form only
+        if (!ce_uniform || !ch_uniform) return false;  // 8 steps over array materials: k_bulk
         if (level_split >= 0) return level_split != 0;
         return (long long)std::max(0, band_hi - band_lo) * cols < 10000000LL;
     }
+    // Launch shapes measured on this GPU for (pass length, first row, last row) of large passes:
+    // band height (0 = the rule in launch_pass) and waves per strip (0 = the rule below).  Filled
+    // by tune_pass() with uncommitted trial launches; results never depend on it.
+    struct Shape {
+        int band_rows, waves;
+    };
+    std::map<std::array<int, 3>, Shape> tuned;
+    int autotune = 1;            // FDTD2D_OPT_AUTOTUNE / FDTD2D_AUTOTUNE=0
+    Shape shape_now{0, 0};       // shape of the launch being issued (set by launch_pass)
+    Shape shape_last{0, 0};      // band height / waves per strip actually used by the last pass
     int split_waves = 0;         // waves per strip in k_bulk_split: 0 = automatic, 4 or 8
     int split_waves_for(int nt, int lo, int hi) const
     {
+        if (!split_waves && shape_now.waves) return shape_now.waves;
         // 16-step passes: 8 waves x 2 levels measured 10 % faster than 4 x 4 at 4096^2, equal
         // or slower from 6144^2 up and for 8-step passes (profiles/r01_split_waves_sweep.txt)
         if (split_waves) return split_waves;
@@ -100,8 +114,8 @@ struct fdtd2d {
         // fill/drain latency: measured faster from 4096^2 up, slower up to 3072^2
         // (profiles/r01_nt16_sweep.txt)
         const bool big = (size_t)nrows * cols >= (size_t)12 << 20;
-        if (max_nt >= 16 && (big || max_nt_forced) && dtype == FDTD2D_F32 && have_mat && ce_uniform &&
-            ch_uniform && boundary == FDTD2D_BOUNDARY_MUR5)
+        if (max_nt >= 16 && (big || max_nt_forced) && dtype == FDTD2D_F32 && have_mat &&
+            boundary == FDTD2D_BOUNDARY_MUR5)
             return 16;
         return std::min(max_nt, 8);
     }

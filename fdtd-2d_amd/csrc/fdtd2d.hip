@@ -429,6 +429,7 @@ int create_impl(fdtd2d_t **out, int rows, int cols, int row0, int nrows, int hal
             return bail(fail(h, FDTD2D_E_NOMEM, "hipMalloc of the PML arrays failed"));
     }
     if (const char *e2 = std::getenv("FDTD2D_BAND_ROWS")) h->stream_band_rows = std::atoi(e2);
+    if (const char *e3 = std::getenv("FDTD2D_AUTOTUNE")) h->autotune = std::atoi(e3) != 0;
     if (const char *e2 = std::getenv("FDTD2D_MAX_NT")) { h->max_nt = std::atoi(e2); h->max_nt_forced = true; }
     if (const char *e2 = std::getenv("FDTD2D_EDGE_DIV")) h->edge_band_div = std::max(1, std::atoi(e2));
     if (const char *e2 = std::getenv("FDTD2D_ZONE_SPLIT")) h->zone_split = std::atoi(e2);
@@ -588,6 +589,8 @@ long long fdtd2d_info(const fdtd2d_t *h, int what)
     case FDTD2D_INFO_PASS_LAUNCHES: return h->pass_launches;
     case FDTD2D_INFO_STEP_LAUNCHES: return h->step_launches;
     case FDTD2D_INFO_CYCLE_STEPS: return h->cycle_steps();
+    case FDTD2D_INFO_LAST_BAND_ROWS: return h->shape_last.band_rows;
+    case FDTD2D_INFO_LAST_WAVES: return h->shape_last.waves;
     default: return FDTD2D_E_ARG;
     }
 }
@@ -747,6 +750,66 @@ int fdtd2d_add_point(fdtd2d_t *h, int row, int col, double amp)
     return rc ? rc : do_add_point(h, row, col, amp);
 }
 
+// Measure the launch shape of a large pass once: trial launches write only into the buffers
+// the next committed pass overwrites anyway (commit = false), so the state is untouched.
+// Candidates: the rule of launch_pass, a ladder of band heights, and for 16-step passes both
+// 4 and 8 waves per strip.  Costs about 40 launches the first time a (length, rows) pair is run.
+static int tune_pass(fdtd2d *h, int nt, int lo, int hi, bool zt, bool zb)
+{
+    const std::array<int, 3> key{nt, lo, hi};
+    if (!h->autotune || h->stream_band_rows > 0 || nt < 8 || h->boundary != FDTD2D_BOUNDARY_MUR5 ||
+        (size_t)std::max(0, hi - lo) * h->cols < ((size_t)4 << 20) || h->tuned.count(key))
+        return 0;
+    std::vector<fdtd2d::Shape> cand{{0, 0}};
+    const bool split = h->use_level_split(nt, lo, hi);
+    const std::vector<int> ladder = nt == 16 ? std::vector<int>{64, 96, 144, 208, 304, 448}
+                                             : std::vector<int>{16, 24, 32, 48, 64, 96, 128};
+    for (int nw : {4, 8}) {
+        if (nw == 8 && !(split && nt == 16 && !h->split_waves)) continue;
+        for (int br : ladder)
+            if (br * 4 <= hi - lo) cand.push_back({br, split && nt == 16 && !h->split_waves ? nw : 0});
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+        if (e0) (void)hipEventDestroy(e0);
+        return fail(h, FDTD2D_E_NOMEM, "hipEventCreate failed");
+    }
+    const long long launches = h->pass_launches;
+    auto trial = [&](const fdtd2d::Shape &c, int reps) {
+        h->tuned[key] = c;
+        int rc = 0;
+        for (int n = 0; n < reps && rc == 0; ++n)
+            rc = h->dtype == FDTD2D_F32
+                     ? launch_pass<float>(h, nt, lo, hi, 0, 0, nullptr, zt, zb, false, lo, hi)
+                     : launch_pass<double>(h, nt, lo, hi, 0, 0, nullptr, zt, zb, false, lo, hi);
+        return rc;
+    };
+    int rc = trial(cand[0], 3);                       // clocks up, code objects loaded
+    fdtd2d::Shape best = cand[0];
+    float best_ms = 1e30f;
+    for (int round = 0; round < 2 && rc == 0; ++round)
+        for (const fdtd2d::Shape &c : cand) {
+            if (round == 0 && (rc = trial(c, 1))) break;          // first use of this kernel variant
+            (void)hipEventRecord(e0, h->stream);
+            if ((rc = trial(c, 2))) break;
+            (void)hipEventRecord(e1, h->stream);
+            float ms = 0;
+            if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) {
+                rc = fail(h, FDTD2D_E_STATE, "timing a trial launch failed");
+                break;
+            }
+            if (ms < best_ms) {
+                best_ms = ms;
+                best = c;
+            }
+        }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    h->pass_launches = launches;
+    h->tuned[key] = rc ? fdtd2d::Shape{0, 0} : best;
+    return rc;
+}
+
 int fdtd2d_run(fdtd2d_t *h, int nsteps, int src_row, int src_col, const double *amps)
 {
     int rc = need_ready(h);
@@ -762,13 +825,14 @@ int fdtd2d_run(fdtd2d_t *h, int nsteps, int src_row, int src_col, const double *
         int nt = 0, lo = 0, hi = 0;
         for (int c : {16, 12, 8, 4, 2, 1})
             if (c <= nsteps - n && (c != 12 || h->max_nt == 12) && (c != 16 || h->cycle_steps() == 16) &&
-                (c <= 8 || (h->dtype == FDTD2D_F32 && h->ce_uniform && h->ch_uniform)) &&
+                (c <= 8 || (h->dtype == FDTD2D_F32 && (c == 16 || (h->ce_uniform && h->ch_uniform)))) &&
                 pass_geometry(h, c, &lo, &hi)) {
                 nt = c;
                 break;
             }
         if (nt) {
             const double *a = amps ? amps + n : nullptr;
+            if ((rc = tune_pass(h, nt, lo, hi, h->top(), h->bottom()))) return rc;
             rc = h->dtype == FDTD2D_F32
                      ? launch_pass<float>(h, nt, lo, hi, src_row, src_col, a, h->top(), h->bottom(), true, lo, hi)
                      : launch_pass<double>(h, nt, lo, hi, src_row, src_col, a, h->top(), h->bottom(), true, lo, hi);
@@ -795,7 +859,7 @@ int fdtd2d_pass_rows(fdtd2d_t *h, int nt, int row_lo, int row_hi, int src_row, i
     if (nt != 1 && nt != 2 && nt != 4 && nt != 8 && nt != 16)
         return fail(h, FDTD2D_E_ARG, "pass length must be 1, 2, 4, 8 or 16");
     if (nt == 16 && h->cycle_steps() != 16)
-        return fail(h, FDTD2D_E_STATE, "16-step passes need float32, uniform materials and the Mur frame");
+        return fail(h, FDTD2D_E_STATE, "16-step passes need float32 and the Mur frame");
     int lo = 0, hi = 0;
     if (!pass_geometry(h, nt, &lo, &hi))
         return fail(h, FDTD2D_E_STATE, "a %d-step pass is not possible from the current state "
@@ -814,6 +878,7 @@ int fdtd2d_pass_rows(fdtd2d_t *h, int nt, int row_lo, int row_hi, int src_row, i
         return fail(h, FDTD2D_E_ARG, "rows cut through the bottom zone [%d,%d)", h->rows - zo, h->rows);
     const bool zt = h->top() && row_lo == 0, zb = h->bottom() && row_hi == h->rows;
     const int b_lo = std::max(row_lo, lo), b_hi = std::min(row_hi, hi);
+    if ((rc = tune_pass(h, nt, b_lo, b_hi, zt, zb))) return rc;
     rc = h->dtype == FDTD2D_F32
              ? launch_pass<float>(h, nt, b_lo, b_hi, src_row, src_col, amps, zt, zb, false, lo, hi)
              : launch_pass<double>(h, nt, b_lo, b_hi, src_row, src_col, amps, zt, zb, false, lo, hi);
@@ -901,6 +966,10 @@ int fdtd2d_set_option(fdtd2d_t *h, int option, long long value)
     case FDTD2D_OPT_LEVEL_SPLIT:
         if (value < -1 || value > 1) return fail(h, FDTD2D_E_ARG, "level split must be -1, 0 or 1");
         h->level_split = (int)value;
+        return 0;
+    case FDTD2D_OPT_AUTOTUNE:
+        h->autotune = value != 0;
+        h->tuned.clear();
         return 0;
     case FDTD2D_OPT_SPLIT_WAVES:
         if (value != 0 && value != 4 && value != 8) return fail(h, FDTD2D_E_ARG, "split waves must be 0, 4 or 8");

@@ -1,4 +1,4 @@
-// Level-split variant of the temporally blocked pass (uniform materials, 8 steps per launch).
+// Level-split variant of the temporally blocked pass (8 or 16 steps per launch).
 //
 // k_bulk (kernels_stream.hpp) lets ONE wave carry all 8 time levels of a (band, strip): 12 row
 // slots = 144 VGPRs, 3 waves per SIMD, and to keep ~3000 waves busy on a 4096^2 grid the bands
@@ -27,16 +27,17 @@ namespace fdtd {
 // grids that cannot fill the GPU otherwise.
 
 // per-lane constants of a strip + the level update (same operations as stream_body)
-template <class T, bool GENERAL, int V> struct StripMath {
+template <class T, bool GENERAL, bool CE_ARR, bool CH_ARR, int V> struct StripMath {
     using VT = VecN<T, V>;
     struct Row {
         VT e, x, y;
+        VT ce, ch;      // coefficient rows travel with the field rows (array materials only)
     };
     const PassParams<T> &p;
     int j0;
     bool ld_ok, has_l, has_r;
     VT ceu, chu;
-    bool in_l[V], in_r[V];
+    bool in_l[V], in_r[V], m_e[V], m_h[V];
 
     __device__ __forceinline__ StripMath(const PassParams<T> &pp, int x0, int lane) : p(pp)
     {
@@ -49,6 +50,8 @@ template <class T, bool GENERAL, int V> struct StripMath {
         for (int v = 0; v < V; ++v) {
             const int j = j0 + v;
             const bool mh = j >= 0 && j <= p.g.C - 2, me = j >= 1 && j <= p.g.C - 2;
+            m_e[v] = me;
+            m_h[v] = mh;
             ceu.v[v] = GENERAL ? (me ? p.ce_u : T(0)) : p.ce_u;
             chu.v[v] = GENERAL ? (mh ? p.ch_u : T(0)) : p.ch_u;
             in_l[v] = j >= 0 && j < 5;
@@ -64,7 +67,7 @@ template <class T, bool GENERAL, int V> struct StripMath {
         if (GENERAL) po = c.e;
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-            const T ch = GENERAL ? chu.v[v] : p.ch_u;
+            const T ch = CH_ARR ? c.ch.v[v] : (GENERAL ? chu.v[v] : p.ch_u);
             const T right = (v + 1 < V) ? c.e.v[v + 1] : e_next_lane;
             c.x.v[v] = c.x.v[v] - ch * (nxe.v[v] - c.e.v[v]);
             c.y.v[v] = c.y.v[v] + ch * (right - c.e.v[v]);
@@ -72,7 +75,7 @@ template <class T, bool GENERAL, int V> struct StripMath {
         const T hy_prev_lane = from_prev(c.y.v[V - 1]);
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-            const T ce = GENERAL ? ceu.v[v] : p.ce_u;
+            const T ce = CE_ARR ? c.ce.v[v] : (GENERAL ? ceu.v[v] : p.ce_u);
             const T left = (v > 0) ? c.y.v[v - 1] : hy_prev_lane;
             c.e.v[v] = c.e.v[v] + ((c.y.v[v] - left) - (c.x.v[v] - pvx.v[v])) * ce;
         }
@@ -110,11 +113,12 @@ template <class T, bool GENERAL, int V> struct StripMath {
 };
 
 // ROLE 0: first wave (HBM -> LDS), 1: middle (LDS -> LDS), 2: last (LDS -> HBM)
-template <class T, int NT, int SPLIT_NW, bool GENERAL, int ROLE, int V>
+template <class T, int NT, int SPLIT_NW, bool CE_ARR, bool CH_ARR, bool GENERAL, int ROLE, int V>
 __device__ __forceinline__ void split_body(const PassParams<T> &p, const int strip, const int ra,
                                            const int rb, const int w, VecN<T, V> *lds)
 {
-    using M = StripMath<T, GENERAL, V>;
+    using M = StripMath<T, GENERAL, CE_ARR, CH_ARR, V>;
+    constexpr int NF = 3 + (CE_ARR ? 1 : 0) + (CH_ARR ? 1 : 0);     // rows per hand-off
     using Row = typename M::Row;
     constexpr int LV = NT / SPLIT_NW, LAG = LV + 1;
     constexpr int HC = stream_hc(NT);
@@ -133,13 +137,14 @@ __device__ __forceinline__ void split_body(const PassParams<T> &p, const int str
     const int shift = w * LAG;                                    // this wave's input row = tau - shift
     const int t0 = w * LV;                                        // level of the input rows
     // hand-off buffers: [hand-off h][parity][field][lane]
-    auto buf = [&](int h, int parity, int field) { return lds + ((h * 2 + parity) * 3 + field) * 64 + lane; };
+    auto buf = [&](int h, int parity, int field) { return lds + ((h * 2 + parity) * NF + field) * 64 + lane; };
 
     Row slot[S];
 #pragma unroll
     for (int k = 0; k < S; ++k)
 #pragma unroll
-        for (int v = 0; v < V; ++v) slot[k].e.v[v] = slot[k].x.v[v] = slot[k].y.v[v] = T(0);
+        for (int v = 0; v < V; ++v)
+            slot[k].e.v[v] = slot[k].x.v[v] = slot[k].y.v[v] = slot[k].ce.v[v] = slot[k].ch.v[v] = T(0);
 
     auto load_global = [&](Row &r, int i) {
         const int ic = min(i, tau1 - 1);
@@ -147,12 +152,16 @@ __device__ __forceinline__ void split_body(const PassParams<T> &p, const int str
         r.e = ldn<V>(p.ez_in + o);
         r.x = ldn<V>(p.hx_in + o);
         r.y = ldn<V>(p.hy_in + o);
+        if (CE_ARR) r.ce = ldn<V>(p.ce + o);
+        if (CH_ARR) r.ch = ldn<V>(p.ch + o);
         if (GENERAL) {
 #pragma unroll
             for (int v = 0; v < V; ++v) {
                 r.e.v[v] = m.ld_ok ? r.e.v[v] : T(0);
                 r.x.v[v] = m.ld_ok ? r.x.v[v] : T(0);
                 r.y.v[v] = m.ld_ok ? r.y.v[v] : T(0);
+                if (CE_ARR) r.ce.v[v] = (m.ld_ok && m.m_e[v]) ? r.ce.v[v] : T(0);
+                if (CH_ARR) r.ch.v[v] = (m.ld_ok && m.m_h[v]) ? r.ch.v[v] : T(0);
             }
         }
     };
@@ -174,6 +183,8 @@ __device__ __forceinline__ void split_body(const PassParams<T> &p, const int str
                 slot[k].e = *buf(w - 1, par, 0);
                 slot[k].x = *buf(w - 1, par, 1);
                 slot[k].y = *buf(w - 1, par, 2);
+                if (CE_ARR) slot[k].ce = *buf(w - 1, par, 3);
+                if (CH_ARR) slot[k].ch = *buf(w - 1, par, NF - 1);
             }
 #pragma unroll
             for (int l = 1; l <= LV; ++l) {
@@ -196,18 +207,21 @@ __device__ __forceinline__ void split_body(const PassParams<T> &p, const int str
                 *buf(w, par, 0) = f.e;
                 *buf(w, par, 1) = f.x;
                 *buf(w, par, 2) = f.y;
+                if (CE_ARR) *buf(w, par, 3) = f.ce;
+                if (CH_ARR) *buf(w, par, NF - 1) = f.ch;
             }
             __syncthreads();
         }
     }
 }
 
-template <class T, int NT, int SPLIT_NW, int V = Vec<T>::N>
+template <class T, int NT, int SPLIT_NW, bool CE_ARR = false, bool CH_ARR = false, int V = Vec<T>::N>
 __global__ __launch_bounds__(64 * SPLIT_NW) void k_bulk_split(const PassParams<T> p)
 {
     static_assert(NT % SPLIT_NW == 0, "levels must divide evenly over the waves");
     constexpr int SW = 64 * V;
-    __shared__ VecN<T, V> lds[(SPLIT_NW - 1) * 2 * 3 * 64];
+    constexpr int NF = 3 + (CE_ARR ? 1 : 0) + (CH_ARR ? 1 : 0);
+    __shared__ VecN<T, V> lds[(SPLIT_NW - 1) * 2 * NF * 64];
     int b = blockIdx.x;
     if (p.fused_zones) {
         // (zone tiles are not fused into this launch: the host always runs k_zone beside it)
@@ -233,18 +247,18 @@ __global__ __launch_bounds__(64 * SPLIT_NW) void k_bulk_split(const PassParams<T
     const bool src = p.src_row >= ra - 2 * NT && p.src_row < rb + NT && p.src_col >= x0 &&
                      p.src_col < x0 + SW;
     // zero the hand-off buffers: the first ticks read rows nobody has written yet
-    for (int n = threadIdx.x; n < (SPLIT_NW - 1) * 2 * 3 * 64; n += 64 * SPLIT_NW)
+    for (int n = threadIdx.x; n < (SPLIT_NW - 1) * 2 * NF * 64; n += 64 * SPLIT_NW)
 #pragma unroll
         for (int v = 0; v < V; ++v) lds[n].v[v] = T(0);
     __syncthreads();
     if (edge || src) {
-        if (w == 0) split_body<T, NT, SPLIT_NW, true, 0, V>(p, strip, ra, rb, w, lds);
-        else if (w == SPLIT_NW - 1) split_body<T, NT, SPLIT_NW, true, 2, V>(p, strip, ra, rb, w, lds);
-        else split_body<T, NT, SPLIT_NW, true, 1, V>(p, strip, ra, rb, w, lds);
+        if (w == 0) split_body<T, NT, SPLIT_NW, CE_ARR, CH_ARR, true, 0, V>(p, strip, ra, rb, w, lds);
+        else if (w == SPLIT_NW - 1) split_body<T, NT, SPLIT_NW, CE_ARR, CH_ARR, true, 2, V>(p, strip, ra, rb, w, lds);
+        else split_body<T, NT, SPLIT_NW, CE_ARR, CH_ARR, true, 1, V>(p, strip, ra, rb, w, lds);
     } else {
-        if (w == 0) split_body<T, NT, SPLIT_NW, false, 0, V>(p, strip, ra, rb, w, lds);
-        else if (w == SPLIT_NW - 1) split_body<T, NT, SPLIT_NW, false, 2, V>(p, strip, ra, rb, w, lds);
-        else split_body<T, NT, SPLIT_NW, false, 1, V>(p, strip, ra, rb, w, lds);
+        if (w == 0) split_body<T, NT, SPLIT_NW, CE_ARR, CH_ARR, false, 0, V>(p, strip, ra, rb, w, lds);
+        else if (w == SPLIT_NW - 1) split_body<T, NT, SPLIT_NW, CE_ARR, CH_ARR, false, 2, V>(p, strip, ra, rb, w, lds);
+        else split_body<T, NT, SPLIT_NW, CE_ARR, CH_ARR, false, 1, V>(p, strip, ra, rb, w, lds);
     }
 }
 

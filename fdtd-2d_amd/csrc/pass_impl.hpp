@@ -19,7 +19,7 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
     const long long bulk = 2LL * p.nbands_e + (long long)p.nbands * std::max(0, p.nstrips - 2);
     const long long zones = (long long)(p.zone_top + p.zone_bot) * p.zone_tiles;
     if (bulk + zones == 0) return 0;
-    if constexpr ((NT == 8 || NT == 16) && !CE_ARR && !CH_ARR) {
+    if constexpr (NT == 16 || (NT == 8 && !CE_ARR && !CH_ARR)) {
         if (h->use_level_split(NT, p.band_lo, p.band_hi)) {     // 4 waves per (band, strip), 2 levels each
             p.fused_zones = 0;
             if (zones > 0) {
@@ -31,12 +31,13 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
                 HIPCHK(h, hipEventRecord(h->ev_join, h->side_stream));
             }
             if (bulk > 0) {
+                // (array materials: one more row per slot and hand-off for each coefficient array)
                 if (h->split_waves_for(NT, p.band_lo, p.band_hi) == 8)
-                    hipLaunchKernelGGL((fdtd::k_bulk_split<T, NT, 8, V>), dim3((unsigned)bulk), dim3(512), 0,
-                                       h->stream, p);
+                    hipLaunchKernelGGL((fdtd::k_bulk_split<T, NT, 8, CE_ARR, CH_ARR, V>), dim3((unsigned)bulk),
+                                       dim3(512), 0, h->stream, p);
                 else
-                    hipLaunchKernelGGL((fdtd::k_bulk_split<T, NT, 4, V>), dim3((unsigned)bulk), dim3(256), 0,
-                                       h->stream, p);
+                    hipLaunchKernelGGL((fdtd::k_bulk_split<T, NT, 4, CE_ARR, CH_ARR, V>), dim3((unsigned)bulk),
+                                       dim3(256), 0, h->stream, p);
                 HIPCHK(h, hipGetLastError());
             }
             if (zones > 0) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
@@ -45,7 +46,7 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
         }
     }
     if constexpr (NT > 12) {
-        return fail(h, FDTD2D_E_ARG, "16-step passes need float32 and uniform materials");
+        return fail(h, FDTD2D_E_ARG, "16- and 12-step passes run on the level-split kernel only");
     } else {
     // Small launches: zone tiles as k_zone on the side stream (ordered behind what is already
     // on h->stream; everything later on h->stream waits for both).  Large launches: fused.
@@ -74,8 +75,8 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
 template <class T, int NT> int launch_pass_nt(fdtd2d *h, fdtd::PassParams<T> &p)
 {
     if (h->ce_uniform && h->ch_uniform) return launch_pass_impl<T, NT, false, false>(h, p);
-    if constexpr (NT > 8)   // the coefficient rows do not fit the register budget beyond 8 levels
-        return fail(h, FDTD2D_E_ARG, "passes longer than 8 steps need uniform materials");
+    if constexpr (NT == 12)   // k_bulk: the coefficient rows do not fit the register budget beyond 8 levels
+        return fail(h, FDTD2D_E_ARG, "12-step passes need uniform materials");
     else {
     if (!h->ce_uniform && h->ch_uniform) return launch_pass_impl<T, NT, true, false>(h, p);
     if (h->ce_uniform && !h->ch_uniform) return launch_pass_impl<T, NT, false, true>(h, p);
@@ -83,7 +84,12 @@ template <class T, int NT> int launch_pass_nt(fdtd2d *h, fdtd::PassParams<T> &p)
     }
 }
 
-// One pass of nt in {1,2,4,8} steps; amps = nt amplitudes or nullptr.
+#ifdef FDTD_PASS_LONG_EXTERN   // the 12- and 16-step float32 kernels are built in pass_f32_long.hip
+extern template int launch_pass_nt<float, 16>(fdtd2d *, fdtd::PassParams<float> &);
+extern template int launch_pass_nt<float, 12>(fdtd2d *, fdtd::PassParams<float> &);
+#endif
+
+// One pass of nt in {1,2,4,8,16} steps; amps = nt amplitudes or nullptr.
 template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, int src_row,
                                    int src_col, const double *amps, bool ztop, bool zbot,
                                    bool commit, int full_lo, int full_hi)
@@ -109,6 +115,14 @@ template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, 
     p.band_hi = band_hi;
     p.nstrips = (h->cols + OW - 1) / OW;
     int br = h->stream_band_rows;
+    h->shape_now = fdtd2d::Shape{0, 0};
+    if (br <= 0) {
+        auto it = h->tuned.find({nt, band_lo, band_hi});
+        if (it != h->tuned.end()) {
+            h->shape_now = it->second;
+            br = it->second.band_rows;
+        }
+    }
     if (br <= 0) {
         // Measured on MI355X (interleaved A/B, profiles/r01_band_sweep.txt): the pass is fastest
         // with about one wave per wave slot (1024 SIMDs x 3 waves) and bands of 16..128 rows:
@@ -132,6 +146,7 @@ template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, 
         }
     }
     p.band_rows = std::max(br, 1);
+    h->shape_last = fdtd2d::Shape{p.band_rows, h->use_level_split(nt, band_lo, band_hi) ? h->split_waves_for(nt, band_lo, band_hi) : 1};
     p.zone_top = ztop;
     p.zone_bot = zbot;
     p.trash = (T *)h->trash;

@@ -256,7 +256,7 @@ class Engine:
         return self
 
     def set_option(self, max_pass_steps=None, band_rows=None, zone_split=None, level_split=None,
-                   split_waves=None):
+                   split_waves=None, autotune=None):
         """Speed knobs of run(): longest temporally blocked pass (0 = single-step kernels
         only) and rows per streaming band.  Results do not depend on them."""
         if max_pass_steps is not None:
@@ -267,6 +267,8 @@ class Engine:
             self._ck(self._lib.fdtd2d_set_option(self._h, _abi.OPT_ZONE_SPLIT, int(zone_split)))
         if level_split is not None:
             self._ck(self._lib.fdtd2d_set_option(self._h, _abi.OPT_LEVEL_SPLIT, int(level_split)))
+        if autotune is not None:
+            self._ck(self._lib.fdtd2d_set_option(self._h, _abi.OPT_AUTOTUNE, int(bool(autotune))))
         if split_waves is not None:
             self._ck(self._lib.fdtd2d_set_option(self._h, _abi.OPT_SPLIT_WAVES, int(split_waves)))
         return self

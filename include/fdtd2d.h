@@ -79,6 +79,8 @@ typedef struct fdtd2d fdtd2d_t;
 #define FDTD2D_INFO_STEP        15 /* completed E half-steps since create/upload */
 #define FDTD2D_INFO_PASS_LAUNCHES 16 /* temporally blocked pass kernels launched so far */
 #define FDTD2D_INFO_STEP_LAUNCHES 17 /* single half-step kernels launched so far */
+#define FDTD2D_INFO_LAST_BAND_ROWS 19 /* band height of the last temporally blocked pass */
+#define FDTD2D_INFO_LAST_WAVES    20 /* its waves per (band, strip): 1 (k_bulk), 4 or 8 (k_bulk_split) */
 #define FDTD2D_INFO_CYCLE_STEPS   18 /* longest pass the current configuration runs: 16 (float32,
                                          uniform materials, Mur frame), else 8, 0 if passes are off */
 
@@ -206,6 +208,10 @@ int fdtd2d_sync(fdtd2d_t *h);
                                          bulk launch, 1 zone tiles as their own kernel on a side stream */
 #define FDTD2D_OPT_SPLIT_WAVES    4   /* waves per band/strip in the level-split kernel: 0 automatic
                                          (default), 4 or 8 */
+#define FDTD2D_OPT_AUTOTUNE       5   /* 1 (default): the first pass of >= 8 steps over >= 4 Mi cells
+                                         times a ladder of band heights (and 4 / 8 waves per strip)
+                                         with uncommitted trial launches and keeps the fastest;
+                                         0: fixed rules.  Results are identical either way. */
 int fdtd2d_set_option(fdtd2d_t *h, int option, long long value);
 
 /* ---- row-slab halo exchange (transport is the caller's: RCCL via torch.distributed) -- */

@@ -440,6 +440,61 @@ def test_every_kernel_variant_matches_oracle(fd, onp, tag, dtype, level_split, z
         assert np.array_equal(a, b), f"{k} level_split={level_split} zone_split={zone_split} {arrays} {tag}"
 
 
+@pytest.mark.parametrize("kind", ["eps", "mu", "eps+mu"])
+@pytest.mark.parametrize("shape", [(76, 64), (100, 225), (130, 470), (200, 1000)])
+@pytest.mark.parametrize("src", [(0, 0), (21, 223), (60, 100)])
+def test_16_step_passes_array_materials(fd, onp, shape, src, kind):
+    """16-step passes over eps and/or mu arrays (the coefficient rows travel with the field rows
+    through the 8 waves of a strip), float32, random state; 35 steps = 16 + 16 + 2 + 1."""
+    r, c = shape
+    rng = np.random.default_rng(r * c + 1)
+    Ez, Hx, Hy, eps, mu = _random_state(rng, r, c, np.float32, onp, vary_mu=(kind != "eps"))
+    if kind == "mu":
+        eps = np.full((r, c), 2.2 * onp.EPS0, np.float32)
+    n = 35
+    amps = rng.standard_normal(n)
+    sr, sc = min(src[0], r - 1), min(src[1], c - 1)
+    ref = [a.copy() for a in (Ez, Hx, Hy)]
+    onp.leapfrog(*ref, eps, mu, DT, DX, n, sr, sc, amps=amps)
+    with fd.Engine(r, c, DT, DX, dtype=np.float32) as eng:
+        eng.set_materials(eps, mu, allow_uniform=False).set_option(max_pass_steps=16, band_rows=40)
+        eng.upload(Ez, Hx, Hy)
+        eng.run(n, sr, sc, amps)
+        got = eng.download()
+        assert eng.info(16) == 4
+    for a, b, k in zip(got, ref, ("Ez", "Hx", "Hy")):
+        assert np.array_equal(a, b), f"{k} {shape} src={src} {kind}: {np.argwhere(a != b)[:4]}"
+
+
+def test_randomised_geometries_float32_long_passes(fd, onp):
+    """30 random float32 configurations with the 16-step pass enabled at every size: grid shape,
+    materials, band height, waves per strip, step count, source anywhere."""
+    rng = np.random.default_rng(20261005)
+    for case in range(30):
+        r = int(rng.integers(76, 180))
+        c = int(rng.choice([rng.integers(16, 60), rng.integers(200, 260), rng.integers(420, 470),
+                            rng.integers(660, 700)]))
+        n = int(rng.integers(16, 50))
+        band = int(rng.choice([0, 17, 48, 64]))
+        nw = int(rng.choice([4, 8]))
+        kind = rng.choice(["uniform", "eps", "eps+mu"])
+        Ez, Hx, Hy, eps, mu = _random_state(rng, r, c, np.float32, onp, vary_mu=(kind == "eps+mu"))
+        if kind == "uniform":
+            eps = np.full((r, c), 1.7 * onp.EPS0, np.float32)
+        sr, sc = int(rng.integers(0, r)), int(rng.integers(0, c))
+        amps = rng.standard_normal(n)
+        ref = [a.copy() for a in (Ez, Hx, Hy)]
+        onp.leapfrog(*ref, eps, mu, DT, DX, n, sr, sc, amps=amps)
+        with fd.Engine(r, c, DT, DX, dtype=np.float32) as eng:
+            eng.set_materials(eps, mu).set_option(max_pass_steps=16, band_rows=band, split_waves=nw)
+            eng.upload(Ez, Hx, Hy)
+            eng.run(n, sr, sc, amps)
+            got = eng.download()
+        for a, b, k in zip(got, ref, ("Ez", "Hx", "Hy")):
+            assert np.array_equal(a, b), (f"case {case}: {k} r={r} c={c} n={n} band={band} nw={nw} "
+                                          f"{kind} src=({sr},{sc}) first diff {np.argwhere(a != b)[:3]}")
+
+
 @pytest.mark.parametrize("split_waves", [4, 8])
 @pytest.mark.parametrize("shape", [(76, 64), (100, 225), (130, 470), (200, 1000)])
 @pytest.mark.parametrize("src", [(0, 0), (20, 30), (21, 223), (60, 100)])

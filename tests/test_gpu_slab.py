@@ -24,6 +24,7 @@ DT, DX = 5e-14, 1e-4
     (2, (160, 700), "float32", "uniform", True, {"max_pass_steps": 16}),    # 16 steps per exchange
     (3, (300, 1100), "float32", "uniform", True, {"max_pass_steps": 16}),
     (2, (160, 700), "float32", "uniform", False, {"max_pass_steps": 16}),
+    (2, (170, 600), "float32", "array", True, {"max_pass_steps": 16}),
 ])
 def test_gpu_slabs_match_single_engine_and_oracle(tmp_path, world, shape, dtype, materials, overlap,
                                                   options):

@@ -215,16 +215,30 @@ __device__ __forceinline__ void split_body(const PassParams<T> &p, const int str
     }
 }
 
-template <class T, int NT, int SPLIT_NW, bool CE_ARR = false, bool CH_ARR = false, int V = Vec<T>::N>
+// FUSE: the zone tiles are the first workgroups of the launch and share its LDS allocation (a
+// workgroup is either a tile or a strip).  That saves the side-stream k_zone launch and its two
+// cross-stream event waits per pass; the build without the zone code serves zone_split = 1.
+template <class T, int NT, int SPLIT_NW, bool FUSE, bool CE_ARR = false, bool CH_ARR = false, int V = Vec<T>::N>
 __global__ __launch_bounds__(64 * SPLIT_NW) void k_bulk_split(const PassParams<T> p)
 {
     static_assert(NT % SPLIT_NW == 0, "levels must divide evenly over the waves");
     constexpr int SW = 64 * V;
     constexpr int NF = 3 + (CE_ARR ? 1 : 0) + (CH_ARR ? 1 : 0);
-    __shared__ VecN<T, V> lds[(SPLIT_NW - 1) * 2 * NF * 64];
+    // one LDS allocation, used either as the hand-off buffers of a strip or as a zone tile
+    constexpr int HAND = (SPLIT_NW - 1) * 2 * NF * 64;                                  // VecN units
+    constexpr int ZONE = !FUSE ? 0 : (ZoneDims<NT>::LDS_ELEMS * (int)sizeof(T) + (int)sizeof(VecN<T, V>) - 1) /
+                                         (int)sizeof(VecN<T, V>);
+    __shared__ VecN<T, V> lds[HAND > ZONE ? HAND : ZONE];
     int b = blockIdx.x;
-    if (p.fused_zones) {
-        // (zone tiles are not fused into this launch: the host always runs k_zone beside it)
+    if constexpr (FUSE) {    // zone tiles are the first workgroups of the launch (all NW waves per tile)
+        const int nzone = (p.zone_top + p.zone_bot) * p.zone_tiles;
+        if (b < nzone) {
+            const int z = b / p.zone_tiles;
+            zone_body<T, NT, CE_ARR, CH_ARR, 64 * SPLIT_NW>(p, b - z * p.zone_tiles, p.zone_top ? z == 1 : true,
+                                                            reinterpret_cast<T *>(lds));
+            return;
+        }
+        b -= nzone;
     }
     int strip, ra, rb;
     if (b < 2 * p.nbands_e) {
@@ -247,7 +261,7 @@ __global__ __launch_bounds__(64 * SPLIT_NW) void k_bulk_split(const PassParams<T
     const bool src = p.src_row >= ra - 2 * NT && p.src_row < rb + NT && p.src_col >= x0 &&
                      p.src_col < x0 + SW;
     // zero the hand-off buffers: the first ticks read rows nobody has written yet
-    for (int n = threadIdx.x; n < (SPLIT_NW - 1) * 2 * NF * 64; n += 64 * SPLIT_NW)
+    for (int n = threadIdx.x; n < HAND; n += 64 * SPLIT_NW)
 #pragma unroll
         for (int v = 0; v < V; ++v) lds[n].v[v] = T(0);
     __syncthreads();

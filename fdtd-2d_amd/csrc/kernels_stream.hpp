@@ -301,6 +301,7 @@ template <int NT> struct ZoneDims {
     static constexpr int WL = NT <= 8 ? 32 : 64;   // columns held in LDS (a power of two >= 2 M + 8)
     static constexpr int WZ = WL - 2 * M;      // columns written per tile
     static constexpr int WLP = WL + 1;         // padded LDS row
+    static constexpr int LDS_ELEMS = 4 * ZR * WLP;   // Ez (two buffers), Hx, Hy
 };
 
 template <class T, bool CE_ARR> struct TileAcc {
@@ -316,14 +317,20 @@ template <class T, bool CE_ARR> struct TileAcc {
     __device__ __forceinline__ T ce(int i, int j) const { return CE_ARR ? cearr[at(g, i, j)] : ce_u; }
 };
 
+// smem: ZoneDims<NT>::LDS_ELEMS elements of LDS owned by the calling kernel (k_bulk_split shares
+// the allocation with its hand-off buffers: a workgroup is either a zone tile or a strip)
 template <class T, int NT, bool CE_ARR, bool CH_ARR, int THREADS>
-__device__ __forceinline__ void zone_body(const PassParams<T> &p, const int tile, const bool bottom)
+__device__ __forceinline__ void zone_body(const PassParams<T> &p, const int tile, const bool bottom,
+                                          T *smem)
 {
     using D = ZoneDims<NT>;
     static_assert((D::WL & (D::WL - 1)) == 0 && THREADS % D::WL == 0 && D::WZ >= 8, "tile shape");
-    __shared__ T sE[2][D::ZR * D::WLP];
-    __shared__ T sX[D::ZR * D::WLP];
-    __shared__ T sY[D::ZR * D::WLP];
+    // (offsets from the one LDS base, never a table of pointers: those become generic pointers,
+    // flat loads, and an out-of-tile read of a masked-off lane -- harmless as a ds_read --
+    // leaves the LDS aperture and faults)
+    constexpr int ZS = D::ZR * D::WLP;
+    T *const sX = smem + 2 * ZS;
+    T *const sY = smem + 3 * ZS;
     const Geom g = p.g;
     // thread -> (row group, column): THREADS/WL tile rows per sweep, no integer division
     constexpr int RG = THREADS / D::WL;
@@ -349,7 +356,7 @@ __device__ __forceinline__ void zone_body(const PassParams<T> &p, const int tile
         if (col_ok && li < D::ZR) {
             const size_t o = at(g, z0 + li, j);
             const int s = li * D::WLP + lj;
-            sE[0][s] = p.ez_in[o];
+            smem[s] = p.ez_in[o];
             sX[s] = p.hx_in[o];
             sY[s] = p.hy_in[o];
         }
@@ -359,8 +366,8 @@ __device__ __forceinline__ void zone_body(const PassParams<T> &p, const int tile
     int cur = 0;
 #pragma unroll 1
     for (int step = 1; step <= NT; ++step) {
-        const T *Eo = sE[cur];
-        T *En = sE[cur ^ 1];
+        const T *Eo = smem + cur * ZS;
+        T *En = smem + (cur ^ 1) * ZS;
         // H half-step (main.py:66-76) on every cell whose i+1 / j+1 neighbours are in the tile
         for (int li = lr; li < D::ZR; li += RG) {
             const int i = z0 + li;
@@ -401,7 +408,7 @@ __device__ __forceinline__ void zone_body(const PassParams<T> &p, const int tile
         cur ^= 1;
     }
 
-    const T *Ef = sE[cur];
+    const T *Ef = smem + cur * ZS;
     for (int r = lr; r < D::ZO; r += RG) {
         const int i = o0 + r;
         if (col_ok && j >= w0 && j < w1) {
@@ -437,8 +444,9 @@ void k_bulk(const PassParams<T> p)
     if (p.fused_zones) {     // zone tiles as the first workgroups of this launch (one wave each)
         const int nzone = (p.zone_top + p.zone_bot) * p.zone_tiles;
         if (b < nzone) {
+            __shared__ T smem[ZoneDims<NT>::LDS_ELEMS];
             const int z = b / p.zone_tiles;
-            zone_body<T, NT, CE_ARR, CH_ARR, 64>(p, b - z * p.zone_tiles, p.zone_top ? z == 1 : true);
+            zone_body<T, NT, CE_ARR, CH_ARR, 64>(p, b - z * p.zone_tiles, p.zone_top ? z == 1 : true, smem);
             return;
         }
         b -= nzone;
@@ -479,8 +487,9 @@ void k_bulk(const PassParams<T> p)
 template <class T, int NT, bool CE_ARR, bool CH_ARR>
 __global__ __launch_bounds__(PASS_THREADS) void k_zone(const PassParams<T> p)
 {
+    __shared__ T smem[ZoneDims<NT>::LDS_ELEMS];
     const int z = blockIdx.x / p.zone_tiles;
-    zone_body<T, NT, CE_ARR, CH_ARR, PASS_THREADS>(p, blockIdx.x - z * p.zone_tiles, p.zone_top ? z == 1 : true);
+    zone_body<T, NT, CE_ARR, CH_ARR, PASS_THREADS>(p, blockIdx.x - z * p.zone_tiles, p.zone_top ? z == 1 : true, smem);
 }
 
 }  // namespace fdtd

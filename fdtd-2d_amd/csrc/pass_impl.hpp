@@ -21,8 +21,13 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
     if (bulk + zones == 0) return 0;
     if constexpr (NT == 16 || (NT == 8 && !CE_ARR && !CH_ARR)) {
         if (h->use_level_split(NT, p.band_lo, p.band_hi)) {     // 4 waves per (band, strip), 2 levels each
-            p.fused_zones = 0;
-            if (zones > 0) {
+            // zone tiles: the first workgroups of the same launch (default: saves the side-stream
+            // launch and two cross-stream event waits per pass -- 38 vs 84 us per 8 steps at
+            // 2048^2, 96 vs 99 at 4096^2, equal at 16384^2: profiles/r01_zone_fuse_split.txt) or
+            // k_zone on the side stream (zone_split = 1)
+            const bool side = zones > 0 && h->zone_split == 1;
+            p.fused_zones = zones > 0 && !side;
+            if (side) {
                 HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
                 HIPCHK(h, hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
                 hipLaunchKernelGGL((fdtd::k_zone<T, NT, CE_ARR, CH_ARR>), dim3((unsigned)zones),
@@ -30,17 +35,21 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
                 HIPCHK(h, hipGetLastError());
                 HIPCHK(h, hipEventRecord(h->ev_join, h->side_stream));
             }
-            if (bulk > 0) {
+            const long long blocks = bulk + (p.fused_zones ? zones : 0);
+            if (blocks > 0) {
                 // (array materials: one more row per slot and hand-off for each coefficient array)
-                if (h->split_waves_for(NT, p.band_lo, p.band_hi) == 8)
-                    hipLaunchKernelGGL((fdtd::k_bulk_split<T, NT, 8, CE_ARR, CH_ARR, V>), dim3((unsigned)bulk),
-                                       dim3(512), 0, h->stream, p);
-                else
-                    hipLaunchKernelGGL((fdtd::k_bulk_split<T, NT, 4, CE_ARR, CH_ARR, V>), dim3((unsigned)bulk),
-                                       dim3(256), 0, h->stream, p);
+                const bool w8 = h->split_waves_for(NT, p.band_lo, p.band_hi) == 8;
+                const dim3 grid((unsigned)blocks), wg(w8 ? 512 : 256);
+                if (p.fused_zones) {
+                    if (w8) hipLaunchKernelGGL((fdtd::k_bulk_split<T, NT, 8, true, CE_ARR, CH_ARR, V>), grid, wg, 0, h->stream, p);
+                    else hipLaunchKernelGGL((fdtd::k_bulk_split<T, NT, 4, true, CE_ARR, CH_ARR, V>), grid, wg, 0, h->stream, p);
+                } else {
+                    if (w8) hipLaunchKernelGGL((fdtd::k_bulk_split<T, NT, 8, false, CE_ARR, CH_ARR, V>), grid, wg, 0, h->stream, p);
+                    else hipLaunchKernelGGL((fdtd::k_bulk_split<T, NT, 4, false, CE_ARR, CH_ARR, V>), grid, wg, 0, h->stream, p);
+                }
                 HIPCHK(h, hipGetLastError());
             }
-            if (zones > 0) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
+            if (side) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
             h->pass_launches++;
             return 0;
         }

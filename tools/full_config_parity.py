@@ -22,6 +22,7 @@ for name, n, steps, eps_fn in (("config 2: 4096x4096 uniform", 4096, 2000, None)
         eng.run(steps, sr, sc, amps)
         got = eng.download()
         launches = eng.info(16)
+        shape = (eng.cycle_steps, eng.info(19), eng.info(20))
     t1 = time.time()
     ref = onp.grid_zeros(n, n, np.float32)
     for d in range(0, steps, 100):                       # progress lines keep the run alive
@@ -30,7 +31,8 @@ for name, n, steps, eps_fn in (("config 2: 4096x4096 uniform", 4096, 2000, None)
         print(f"  oracle at step {d + k} ({time.time() - t1:.0f}s)", flush=True)
     t2 = time.time()
     same = [bool(np.array_equal(a, b)) for a, b in zip(got, ref)]
-    print(f"{name}, {steps} steps: device {t1 - t0:.1f}s ({launches} pass launches), C oracle "
+    print(f"{name}, {steps} steps: device {t1 - t0:.1f}s ({launches} pass launches; {shape[0]}-step "
+          f"passes, bands of {shape[1]} rows, {shape[2]} waves per strip), C oracle "
           f"({c_oracle.num_threads()} threads) {t2 - t1:.1f}s, max|Ez| {np.abs(ref[0]).max():.6g}, "
           f"Ez/Hx/Hy identical: {same}", flush=True)
     assert all(same)

@@ -78,15 +78,17 @@ struct fdtd2d {
     void *hx() const { return hxb[hcur]; }
     void *hy() const { return hyb[hcur]; }
     int stream_band_rows = 0;    // 0 = heuristic (FDTD2D_BAND_ROWS overrides)
-    int level_split = -1;        // k_bulk_split for 8-step passes with uniform materials: -1 = on slabs
-                                 // below ~10 M cells (measured faster there), 0 never, 1 always
+    int level_split = -1;        // k_bulk_split for 8-step passes: -1 / 1 = yes (measured faster than
+                                 // k_bulk at every size, float32 and float64:
+                                 // profiles/r01_split8_vs_bulk.txt), 0 = k_bulk
     bool use_level_split(int nt, int band_lo, int band_hi) const
     {
+        (void)band_lo, (void)band_hi;
         if ((nt != 8 && nt != 16) || boundary != FDTD2D_BOUNDARY_MUR5) return false;
         if (nt == 16) return dtype == FDTD2D_F32;      // 16-step passes exist in this form only
-        if (!ce_uniform || !ch_uniform) return false;  // 8 steps over array materials: k_bulk
-        if (level_split >= 0) return level_split != 0;
-        return (long long)std::max(0, band_hi - band_lo) * cols < 10000000LL;
+        // array materials: only the build with fused zone tiles exists
+        if ((!ce_uniform || !ch_uniform) && zone_split == 1) return false;
+        return level_split != 0;
     }
     // Launch shapes measured on this GPU for (pass length, first row, last row) of large passes:
     // band height (0 = the rule in launch_pass) and waves per strip (0 = the rule below).  Filled

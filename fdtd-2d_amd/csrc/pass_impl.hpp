@@ -19,7 +19,7 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
     const long long bulk = 2LL * p.nbands_e + (long long)p.nbands * std::max(0, p.nstrips - 2);
     const long long zones = (long long)(p.zone_top + p.zone_bot) * p.zone_tiles;
     if (bulk + zones == 0) return 0;
-    if constexpr (NT == 16 || (NT == 8 && !CE_ARR && !CH_ARR)) {
+    if constexpr (NT == 16 || NT == 8) {
         if (h->use_level_split(NT, p.band_lo, p.band_hi)) {     // 4 waves per (band, strip), 2 levels each
             // zone tiles: the first workgroups of the same launch (default: saves the side-stream
             // launch and two cross-stream event waits per pass -- 38 vs 84 us per 8 steps at
@@ -40,12 +40,16 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
                 // (array materials: one more row per slot and hand-off for each coefficient array)
                 const bool w8 = h->split_waves_for(NT, p.band_lo, p.band_hi) == 8;
                 const dim3 grid((unsigned)blocks), wg(w8 ? 512 : 256);
-                if (p.fused_zones) {
+                // (a piece without zone tiles can run on either build; 8-step passes over array
+                // materials only have the fused one)
+                if (p.fused_zones || (!side && NT == 8 && (CE_ARR || CH_ARR))) {
                     if (w8) hipLaunchKernelGGL((fdtd::k_bulk_split<T, NT, 8, true, CE_ARR, CH_ARR, V>), grid, wg, 0, h->stream, p);
                     else hipLaunchKernelGGL((fdtd::k_bulk_split<T, NT, 4, true, CE_ARR, CH_ARR, V>), grid, wg, 0, h->stream, p);
-                } else {
+                } else if constexpr (NT == 16 || (!CE_ARR && !CH_ARR)) {
                     if (w8) hipLaunchKernelGGL((fdtd::k_bulk_split<T, NT, 8, false, CE_ARR, CH_ARR, V>), grid, wg, 0, h->stream, p);
                     else hipLaunchKernelGGL((fdtd::k_bulk_split<T, NT, 4, false, CE_ARR, CH_ARR, V>), grid, wg, 0, h->stream, p);
+                } else {
+                    return fail(h, FDTD2D_E_STATE, "8-step level-split passes over array materials are built with fused zones only");
                 }
                 HIPCHK(h, hipGetLastError());
             }

@@ -104,10 +104,11 @@ struct fdtd2d {
     int split_waves_for(int nt, int lo, int hi) const
     {
         if (!split_waves && shape_now.waves) return shape_now.waves;
-        // 16-step passes: 8 waves x 2 levels measured 10 % faster than 4 x 4 at 4096^2, equal
-        // or slower from 6144^2 up and for 8-step passes (profiles/r01_split_waves_sweep.txt)
-        if (split_waves) return split_waves;
-        return nt == 16 && (size_t)std::max(0, hi - lo) * cols < ((size_t)28 << 20) ? 8 : 4;
+        // 4 waves x NT/4 levels.  8 x NT/8 was 10 % faster at 4096^2 while the zone tiles ran as
+        // their own kernel (profiles/r01_split_waves_sweep.txt); with the tiles fused into the
+        // launch the tuner keeps picking 4, and 8 stays one of its candidates.
+        (void)nt, (void)lo, (void)hi;
+        return split_waves ? split_waves : 4;
     }
     bool max_nt_forced = false;  // set_option(MAX_PASS_STEPS): no size rule for 16-step passes
     int cycle_steps() const      // longest pass this configuration runs

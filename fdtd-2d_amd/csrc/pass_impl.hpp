@@ -145,15 +145,15 @@ template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, 
         const bool split4 = h->use_level_split(nt, band_lo, band_hi);
         const int slots = split4 ? 2304 : 3072;     // measured: the level-split kernel likes ~32-row bands too
         const int want = std::max(1, (slots + p.nstrips - 1) / p.nstrips);
-        br = nt > 12 ? std::min(std::max(region / want, 64), 512)       // ~24 ticks of fill per band
+        // 16-step passes: ~58 bands whatever the size is what tune_pass() keeps finding on square
+        // grids (64 rows at 4096^2, 144 at 8192^2, 304 at 16384^2: profiles/r01_autotune.txt)
+        br = nt > 12 ? std::min(std::max((region + 57) / 58, 64), 448)
                      : std::min(std::max(region / want, split4 ? 32 : 16), 128);
-        // Workgroups resident at once: 256 CUs x 4 (16-step, 4 waves each, 117 VGPRs) or x 5
-        // (8-step, 93 VGPRs).  A launch of 1.0-1.6 times that leaves a thin second round; one
-        // round of taller bands measured 5-10 % faster (4096^2 and 2048x8192 at 16 steps, 3072^2
-        // at 8: profiles/r01_band16_sweep.txt, r01_split_waves_sweep.txt).  With 8 waves per
-        // strip the shortest bands were fastest.
-        if (split4 && h->split_waves_for(nt, band_lo, band_hi) == 4) {
-            const int cap = nt > 12 ? 1024 : 1280, fit = std::max(1, (cap * 9 / 10) / p.nstrips);
+        // 8-step level-split passes: 1280 workgroups are resident at once (256 CUs x 5 at 93
+        // VGPRs).  A launch of 1.0-1.6 times that leaves a thin second round; one round of taller
+        // bands measured 5-10 % faster (3072^2: profiles/r01_split_waves_sweep.txt).
+        if (split4 && nt <= 8) {
+            const int cap = 1280, fit = std::max(1, (cap * 9 / 10) / p.nstrips);
             const long long wgs = (long long)((region + br - 1) / br) * p.nstrips;
             if (wgs > cap * 92 / 100 && wgs <= cap * 16 / 10) br = std::max(br, (region + fit - 1) / fit);
         }

@@ -17,6 +17,16 @@ for f in glob.glob(os.path.join(out, "stats", "*", "*kernel_stats.csv")):
         print(f"{row['Name'][:90]:90s} calls={row['Calls']:>5s} avg_ns={float(row['AverageNs']):12.0f} "
               f"min_ns={row['MinNs']:>10s} max_ns={row['MaxNs']:>10s} pct={row['Percentage']}")
 print()
+print("== steady state from the kernel trace: last 20 dispatches of each pass kernel ==")
+for f in glob.glob(os.path.join(out, "stats", "*", "*kernel_trace.csv")):
+    per = collections.defaultdict(list)
+    for row in csv.DictReader(open(f)):
+        if "k_bulk" in row["Kernel_Name"] or "k_pass" in row["Kernel_Name"]:
+            per[row["Kernel_Name"]].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+    for k, v in per.items():
+        w = v[-20:]
+        print(f"{k[:90]:90s} n={len(v):4d} last{len(w)}_avg_ns={sum(w)/len(w):12.0f}")
+print()
 print("== PMC (separate passes; KiB per dispatch as reported) ==")
 acc = collections.defaultdict(list)
 for leg in ("pmc_fetch", "pmc_write"):

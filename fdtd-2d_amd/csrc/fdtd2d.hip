@@ -609,6 +609,7 @@ int fdtd2d_set_materials(fdtd2d_t *h, const void *eps, const void *mu, int host_
     if (!eps || !mu) return fail(h, FDTD2D_E_ARG, "eps and mu must not be NULL");
     if (host_dtype != FDTD2D_F32 && host_dtype != FDTD2D_F64)
         return fail(h, FDTD2D_E_ARG, "bad host_dtype");
+    h->tuned.clear();     // the kernel variant may change with the material layout
     int rc = use_device(h);
     if (rc) return rc;
     return h->dtype == FDTD2D_F32
@@ -620,6 +621,7 @@ int fdtd2d_set_materials_uniform(fdtd2d_t *h, double eps, double mu)
 {
     if (!h) return FDTD2D_E_ARG;
     if (!(eps > 0) || !(mu > 0)) return fail(h, FDTD2D_E_ARG, "eps and mu must be positive");
+    h->tuned.clear();
     int rc = use_device(h);
     if (rc) return rc;
     for (void **p : {&h->ce, &h->ch})
@@ -966,6 +968,7 @@ int fdtd2d_set_option(fdtd2d_t *h, int option, long long value)
     case FDTD2D_OPT_LEVEL_SPLIT:
         if (value < -1 || value > 1) return fail(h, FDTD2D_E_ARG, "level split must be -1, 0 or 1");
         h->level_split = (int)value;
+        h->tuned.clear();
         return 0;
     case FDTD2D_OPT_AUTOTUNE:
         h->autotune = value != 0;
@@ -974,10 +977,12 @@ int fdtd2d_set_option(fdtd2d_t *h, int option, long long value)
     case FDTD2D_OPT_SPLIT_WAVES:
         if (value != 0 && value != 4 && value != 8) return fail(h, FDTD2D_E_ARG, "split waves must be 0, 4 or 8");
         h->split_waves = (int)value;
+        h->tuned.clear();
         return 0;
     case FDTD2D_OPT_ZONE_SPLIT:
         if (value < -1 || value > 1) return fail(h, FDTD2D_E_ARG, "zone split must be -1, 0 or 1");
         h->zone_split = (int)value;
+        h->tuned.clear();
         return 0;
     default: return fail(h, FDTD2D_E_ARG, "unknown option %d", option);
     }

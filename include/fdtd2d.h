@@ -81,8 +81,8 @@ typedef struct fdtd2d fdtd2d_t;
 #define FDTD2D_INFO_STEP_LAUNCHES 17 /* single half-step kernels launched so far */
 #define FDTD2D_INFO_LAST_BAND_ROWS 19 /* band height of the last temporally blocked pass */
 #define FDTD2D_INFO_LAST_WAVES    20 /* its waves per (band, strip): 1 (k_bulk), 4 or 8 (k_bulk_split) */
-#define FDTD2D_INFO_CYCLE_STEPS   18 /* longest pass the current configuration runs: 16 (float32,
-                                         uniform materials, Mur frame), else 8, 0 if passes are off */
+#define FDTD2D_INFO_CYCLE_STEPS   18 /* longest pass the current configuration runs: 16 (float32, Mur
+                                         frame, >= 12 Mi cells per GPU), else 8, 0 if passes are off */
 
 /* ---- lifetime ------------------------------------------------------------------ */
 
@@ -192,20 +192,21 @@ int fdtd2d_sync(fdtd2d_t *h);
 
 /* Tuning knobs of fdtd2d_run (results do not depend on them, only speed):
  *   FDTD2D_OPT_MAX_PASS_STEPS  longest temporally blocked pass, 0..16 (0 = plain single steps
- *                              with the half-step kernels); default 16.  16-step passes (level-
- *                              split kernel) exist for float32 with uniform materials and the
- *                              Mur frame; everything else runs 8-step passes.  By default they
- *                              are used from 12 Mi cells per GPU up (faster from 4096^2, slower
- *                              below: profiles/r01_nt16_sweep.txt); setting this option to 16
+ *                              with the half-step kernels); default 16.  16-step passes exist
+ *                              for float32 with the Mur frame (uniform or array materials);
+ *                              everything else runs 8-step passes.  By default they are used
+ *                              from 12 Mi cells per GPU up (faster from 4096^2, slower below:
+ *                              profiles/r01_nt16_sweep.txt); setting this option to 16
  *                              explicitly uses them at every size.
  *   FDTD2D_OPT_BAND_ROWS       rows per streaming band (0 = heuristic) */
 #define FDTD2D_OPT_MAX_PASS_STEPS 0
 #define FDTD2D_OPT_BAND_ROWS      1
-#define FDTD2D_OPT_LEVEL_SPLIT    3   /* 8-step passes over uniform materials with the level-split kernel
-                                         (4 waves per band/strip, rows handed over through LDS):
-                                         -1 below ~10 M cells (default), 0 never, 1 always */
-#define FDTD2D_OPT_ZONE_SPLIT     2   /* -1 by launch size (default), 0 zone tiles fused into the
-                                         bulk launch, 1 zone tiles as their own kernel on a side stream */
+#define FDTD2D_OPT_LEVEL_SPLIT    3   /* 8-step passes with the level-split kernel (4 waves per band/strip,
+                                         rows handed over through LDS): -1 / 1 yes (default), 0 the
+                                         single-wave kernel.  16-step passes always use it. */
+#define FDTD2D_OPT_ZONE_SPLIT     2   /* top/bottom zone tiles: 0 fused into the pass launch, 1 their own
+                                         kernel on a side stream, -1 (default) fused for the level-split
+                                         kernel and by launch size for the single-wave kernel */
 #define FDTD2D_OPT_SPLIT_WAVES    4   /* waves per band/strip in the level-split kernel: 0 automatic
                                          (default), 4 or 8 */
 #define FDTD2D_OPT_AUTOTUNE       5   /* 1 (default): the first pass of >= 8 steps over >= 4 Mi cells

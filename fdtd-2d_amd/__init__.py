@@ -8,8 +8,9 @@ from .api import (EPS0, MU0, capture_snapshot, courant_number, grid_init, materi
                   sinusoidal_amplitude, snapshot_indices, eps_background, step, update_Ez,
                   update_Hx_Hy)
 from .engine import Engine  # noqa: F401
+from .structure import Structure, ring_resonator  # noqa: F401
 
-__all__ = ["Engine", "Fdtd2dError", "EPS0", "MU0", "grid_init", "material_init", "ricker",
+__all__ = ["Engine", "Structure", "ring_resonator", "Fdtd2dError", "EPS0", "MU0", "grid_init", "material_init", "ricker",
            "sinusoidal", "ricker_amplitude", "sinusoidal_amplitude", "courant_number",
            "update_Hx_Hy", "update_Ez", "step", "run_fdtd", "capture_snapshot", "render_snapshot",
            "snapshot_indices", "eps_background", "pml_profiles"]

@@ -175,6 +175,21 @@ def main():
         np.savez_compressed(os.path.join(OUT, f"n1_snapshot_{tag}.npz"), rgb=rgb, rgb_uniform=rgb_u,
                             vmax=1e-3, vmin=-1e-3, vmax_u=0.2, vmin_u=-0.2)
 
+    # N2: the reference's structure canvas (region_drawer.py:5-87) -- every primitive once
+    import region_drawer as rd
+    cv = rd.RegionDrawer(160, 120)
+    cv.draw_waveguide((0, 20), (159, 20), 6)
+    cv.draw_waveguide((10, 110), (150, 95), 5)
+    cv.draw_ring_resonator((70, 66), 30, 5)
+    cv.draw_sphere((135, 60), 9, 4)
+    cv.draw_curved_waveguide((5, 40), (60, 115), (8, 100), 4)
+    cv.draw_directional_coupler((90, 108), 60, 7, 3)
+    png = os.path.join(tempfile.mkdtemp(prefix="fdtd_canvas_"), "canvas.png")
+    cv.save(png)
+    e, m = ref.material_init(png, 90, 128, 6.0)
+    np.savez_compressed(os.path.join(OUT, "n2_structure_canvas.npz"), pixels=np.array(Image.open(png)),
+                        eps=e, mu=m, rows=90, cols=128, black_point=6.0)
+
     print("golden vectors written to", OUT)
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):

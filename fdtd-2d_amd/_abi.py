@@ -48,6 +48,7 @@ SIGNATURES = {
     "fdtd2d_update_h": (_i, [_vp]),
     "fdtd2d_update_e": (_i, [_vp]),
     "fdtd2d_add_point": (_i, [_vp, _i, _i, _d]),
+    "fdtd2d_set_source_extent": (_i, [_vp, _i, _i]),
     "fdtd2d_run": (_i, [_vp, _i, _i, _i, C.POINTER(_d)]),
     "fdtd2d_pass_rows": (_i, [_vp, _i, _i, _i, _i, _i, C.POINTER(_d)]),
     "fdtd2d_pass_commit": (_i, [_vp]),

@@ -251,7 +251,8 @@ def run_fdtd(rows=200, cols=200, dt=5e-14, dx=1e-4, nsteps=1000, eps=None, mu=No
     H -> E -> source with t = i*dt, fields resident on the GPU throughout.
 
     eps/mu: None (vacuum), scalars or (rows, cols) arrays.  source: (kind, row, col, fc)
-    with row/col None = grid centre (fdtd.py:34), or None.  on_frame(i, Ez) is called
+    with row/col None = grid centre (fdtd.py:34), or None; an optional fifth element
+    (nrows, ncols) makes it a line / patch source starting at (row, col).  on_frame(i, Ez) is called
     every nsteps//nframes steps with a host copy of Ez (the snapshot cadence of
     fdtd.py:36-38).  Returns (Ez, Hx, Hy) as host arrays of `dtype`.
     """
@@ -271,9 +272,11 @@ def run_fdtd(rows=200, cols=200, dt=5e-14, dx=1e-4, nsteps=1000, eps=None, mu=No
             eng.set_pml(courant00=(1 / np.sqrt(float(e00) * float(m00)) * dt) / dx)
         amps, sr, sc = None, 0, 0
         if source is not None:
-            kind, sr, sc, fc = source
+            kind, sr, sc, fc, *extent = source
             sr = rows // 2 if sr is None else sr
             sc = cols // 2 if sc is None else sc
+            if extent:
+                eng.set_source_extent(*extent[0])
             f = {"ricker": ricker_amplitude, "sinusoidal": sinusoidal_amplitude}[kind]
             amps = np.array([f(i * dt, fc) for i in range(nsteps)], dtype=np.float64)
         every = max(1, nsteps // nframes) if on_frame is not None else nsteps

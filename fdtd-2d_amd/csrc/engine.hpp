@@ -55,6 +55,7 @@ struct fdtd2d {
     Range ev{0, 0}, hv{0, 0};    // global rows on which Ez / (Hx,Hy) are current
     long long step = 0;
     long long pass_launches = 0, step_launches = 0;
+    int src_rows = 1, src_cols = 1;   // extent of the source: (row, col) of run/add_point is its first cell
     // a pass issued in pieces (fdtd2d_pass_rows) and not yet committed
     int pend_nt = 0;
     std::vector<Range> pend_done;

@@ -213,8 +213,12 @@ template <class T> int launch_e(fdtd2d *h, int lo, int hi)
 template <class T> int launch_point(fdtd2d *h, int row, int col, double amp)
 {
     const Geom g = h->geom();
-    hipLaunchKernelGGL((fdtd::k_add_point<T>), dim3(1), dim3(1), 0, h->stream,
-                       (T *)h->ez[h->cur], fdtd::at(g, row, col), amp);
+    // rows of the source rectangle that are current on this slab
+    const int r0 = std::max(row, h->ev.lo), r1 = std::min(row + h->src_rows, h->ev.hi);
+    if (r0 >= r1) return 0;
+    const int n = (r1 - r0) * h->src_cols;
+    hipLaunchKernelGGL((fdtd::k_add_point<T>), dim3((n + 255) / 256), dim3(n == 1 ? 1 : 256), 0, h->stream,
+                       (T *)h->ez[h->cur], g, r0, col, r1 - r0, h->src_cols, amp);
     HIPCHK(h, hipGetLastError());
     return 0;
 }
@@ -262,10 +266,9 @@ int do_update_e(fdtd2d *h)
 
 int do_add_point(fdtd2d *h, int row, int col, double amp)
 {
-    if (row < 0 || row >= h->rows || col < 0 || col >= h->cols)
-        return fail(h, FDTD2D_E_ARG, "source cell (%d,%d) outside the %dx%d grid", row, col,
-                    h->rows, h->cols);
-    if (row < h->ev.lo || row >= h->ev.hi) return 0;   // not on this slab's current rows
+    if (row < 0 || row + h->src_rows > h->rows || col < 0 || col + h->src_cols > h->cols)
+        return fail(h, FDTD2D_E_ARG, "source (%d,%d)+%dx%d outside the %dx%d grid", row, col,
+                    h->src_rows, h->src_cols, h->rows, h->cols);
     return h->dtype == FDTD2D_F32 ? launch_point<float>(h, row, col, amp)
                                   : launch_point<double>(h, row, col, amp);
 }
@@ -745,6 +748,16 @@ int fdtd2d_update_e(fdtd2d_t *h)
     return rc ? rc : do_update_e(h);
 }
 
+int fdtd2d_set_source_extent(fdtd2d_t *h, int nrows, int ncols)
+{
+    if (!h) return FDTD2D_E_ARG;
+    if (nrows < 1 || ncols < 1 || nrows > h->rows || ncols > h->cols)
+        return fail(h, FDTD2D_E_ARG, "source extent %dx%d does not fit the %dx%d grid", nrows, ncols, h->rows, h->cols);
+    h->src_rows = nrows;
+    h->src_cols = ncols;
+    return 0;
+}
+
 int fdtd2d_add_point(fdtd2d_t *h, int row, int col, double amp)
 {
     if (!h) return FDTD2D_E_ARG;
@@ -818,9 +831,10 @@ int fdtd2d_run(fdtd2d_t *h, int nsteps, int src_row, int src_col, const double *
     if (rc) return rc;
     if (h->pend_nt) return fail(h, FDTD2D_E_STATE, "a partial pass is pending: commit it first");
     if (nsteps < 0) return fail(h, FDTD2D_E_ARG, "nsteps < 0");
-    if (amps && (src_row < 0 || src_row >= h->rows || src_col < 0 || src_col >= h->cols))
-        return fail(h, FDTD2D_E_ARG, "source cell (%d,%d) outside the %dx%d grid", src_row,
-                    src_col, h->rows, h->cols);
+    if (amps && (src_row < 0 || src_row + h->src_rows > h->rows || src_col < 0 ||
+                 src_col + h->src_cols > h->cols))
+        return fail(h, FDTD2D_E_ARG, "source (%d,%d)+%dx%d outside the %dx%d grid", src_row, src_col,
+                    h->src_rows, h->src_cols, h->rows, h->cols);
     int n = 0;
     while (n < nsteps) {
         // longest temporally blocked pass that fits, else one plain step

@@ -256,10 +256,11 @@ __device__ __forceinline__ void pml_body(const PassParams<T> &p, const PmlPass<T
                         c.e.v[v] = me[v] ? (lay ? ex + ey : plain) : c.e.v[v];
                     }
                 }
-                if (i == p.src_row) {
+                if (i >= p.src_row && i < p.src_row1) {
 #pragma unroll
                     for (int v = 0; v < V; ++v)
-                        if (j0 + v == p.src_col) c.e.v[v] = (T)((double)c.e.v[v] + p.amp[t - 1]);
+                        if (j0 + v >= p.src_col && j0 + v < p.src_col1)
+                            c.e.v[v] = (T)((double)c.e.v[v] + p.amp[t - 1]);
                 }
             }
             {
@@ -316,7 +317,7 @@ __global__ __launch_bounds__(64, 2) void k_pass_pml(const PassParams<T> p, const
     // does the wave's cone (rows [ra-2NT, rb+NT), columns [x0, x0+SW)) touch the layer or the edge?
     const bool layer = x0 < L + 1 || x0 + SW > p.g.C - 1 - L || ra - 2 * NT < L + 1 ||
                        rb + NT > p.g.R - 1 - L;
-    const bool src = p.src_row >= ra - 2 * NT && p.src_row < rb + NT && p.src_col >= x0 &&
+    const bool src = p.src_row1 > ra - 2 * NT && p.src_row < rb + NT && p.src_col1 > x0 &&
                      p.src_col < x0 + SW;
     if (layer)
         pml_body<T, NT, CE_ARR>(p, q, strip, ra, rb);

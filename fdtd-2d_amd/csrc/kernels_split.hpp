@@ -102,11 +102,11 @@ template <class T, bool GENERAL, bool CE_ARR, bool CH_ARR, int V> struct StripMa
                 }
                 c.e = out;
             }
-            if (i == p.src_row) {
+            if (i >= p.src_row && i < p.src_row1) {
                 const double amp = p.amp[t - 1];
 #pragma unroll
                 for (int v = 0; v < V; ++v)
-                    if (j0 + v == p.src_col) c.e.v[v] = (T)((double)c.e.v[v] + amp);
+                    if (j0 + v >= p.src_col && j0 + v < p.src_col1) c.e.v[v] = (T)((double)c.e.v[v] + amp);
             }
         }
     }
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(64 * SPLIT_NW) void k_bulk_split(const PassParams<T
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int x0 = strip_x0<T, NT, V>(p, strip);
     const bool edge = x0 < 5 || x0 + SW > p.g.C - 5;
-    const bool src = p.src_row >= ra - 2 * NT && p.src_row < rb + NT && p.src_col >= x0 &&
+    const bool src = p.src_row1 > ra - 2 * NT && p.src_row < rb + NT && p.src_col1 > x0 &&
                      p.src_col < x0 + SW;
     // zero the hand-off buffers: the first ticks read rows nobody has written yet
     for (int n = threadIdx.x; n < HAND; n += 64 * SPLIT_NW)

@@ -183,9 +183,13 @@ __global__ __launch_bounds__(256) void k_frame_mur(FrameCtx<T, CE_ARR> f, T *__r
 }
 
 // ---- point source: fdtd.py:34 ---------------------------------------------------------------
-template <class T> __global__ void k_add_point(T *ez, size_t off, double amp)
+// (one cell, or the same amplitude on every cell of an nr x nc rectangle: a line / patch source)
+template <class T> __global__ void k_add_point(T *ez, Geom g, int row, int col, int nr, int nc, double amp)
 {
-    ez[off] = (T)((double)ez[off] + amp);
+    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < nr * nc; n += gridDim.x * blockDim.x) {
+        const size_t off = at(g, row + n / nc, col + n % nc);
+        ez[off] = (T)((double)ez[off] + amp);
+    }
 }
 
 // ---- coefficient arrays: x -> dt/(x*dx) in T (main.py:27,70,74) ------------------------------

@@ -58,7 +58,8 @@ template <class T> struct PassParams {
     int fused_zones;           // 1: the zone tiles are the first workgroups of the k_bulk launch
                                // (one wave each); 0: k_zone runs them on a side stream
     T *trash;                  // >= 3 x 1 KiB of device scratch: where masked-off stores land
-    int src_row, src_col;      // -1: no source
+    int src_row, src_col;      // first source cell; the source is the rectangle
+    int src_row1, src_col1;    // [src_row, src_row1) x [src_col, src_col1) (all four very negative: none)
     double amp[STREAM_MAX_NT]; // amplitude added after step s = 1..NT of this pass
 };
 
@@ -271,10 +272,11 @@ __device__ __forceinline__ void stream_body(const PassParams<T> &p, const int st
                         }
                         c.e = out;
                     }
-                    if (i == p.src_row) {   // point source after step t of this pass (fdtd.py:34)
+                    if (i >= p.src_row && i < p.src_row1) {   // source after step t of this pass (fdtd.py:34)
 #pragma unroll
                         for (int v = 0; v < V; ++v)
-                            if (j0 + v == p.src_col) c.e.v[v] = (T)((double)c.e.v[v] + p.amp[t - 1]);
+                            if (j0 + v >= p.src_col && j0 + v < p.src_col1)
+                                c.e.v[v] = (T)((double)c.e.v[v] + p.amp[t - 1]);
                     }
                 }
             }
@@ -400,7 +402,8 @@ __device__ __forceinline__ void zone_body(const PassParams<T> &p, const int tile
                         val = val + ((sY[s] - sY[s - 1]) - (sX[s] - sX[s - D::WLP])) * ce;
                     }
                 }
-                if (i == p.src_row && j == p.src_col) val = (T)((double)val + p.amp[step - 1]);
+                if (i >= p.src_row && i < p.src_row1 && j >= p.src_col && j < p.src_col1)
+                    val = (T)((double)val + p.amp[step - 1]);
                 En[s] = val;
             }
         }
@@ -472,7 +475,7 @@ void k_bulk(const PassParams<T> p)
     // wave-uniform choice: all SW columns plain interior (5 <= j <= C-6) and the source cell
     // outside the rows/columns this wave ever touches -> mask-free body
     const bool edge = x0 < 5 || x0 + SW > p.g.C - 5;
-    const bool src = p.src_row >= ra - 2 * NT && p.src_row < rb + NT && p.src_col >= x0 &&
+    const bool src = p.src_row1 > ra - 2 * NT && p.src_row < rb + NT && p.src_col1 > x0 &&
                      p.src_col < x0 + SW;
 #ifdef STREAM_EXP_NO_GENERAL
     stream_body<T, NT, CE_ARR, CH_ARR, false, V>(p, strip, ra, rb);   // timing experiment only

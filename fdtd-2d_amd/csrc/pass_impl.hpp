@@ -163,8 +163,11 @@ template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, 
     p.zone_top = ztop;
     p.zone_bot = zbot;
     p.trash = (T *)h->trash;
-    p.src_row = amps ? src_row : -1;
-    p.src_col = amps ? src_col : -1;
+    constexpr int NONE = -(1 << 30);
+    p.src_row = amps ? src_row : NONE;
+    p.src_col = amps ? src_col : NONE;
+    p.src_row1 = amps ? src_row + h->src_rows : NONE;
+    p.src_col1 = amps ? src_col + h->src_cols : NONE;
     for (int s = 0; s < fdtd::STREAM_MAX_NT; ++s) p.amp[s] = (amps && s < nt) ? amps[s] : 0.0;
     int rc;
     if (h->boundary == FDTD2D_BOUNDARY_PML) {

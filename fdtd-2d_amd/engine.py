@@ -221,6 +221,12 @@ class Engine:
     def add_point(self, row, col, amp):
         self._ck(self._lib.fdtd2d_add_point(self._h, int(row), int(col), float(amp)))
 
+    def set_source_extent(self, nrows=1, ncols=1):
+        """Line / patch sources: the source of add_point / run / pass_rows becomes the rectangle
+        of nrows x ncols cells starting at the (row, col) given there (default one cell)."""
+        self._ck(self._lib.fdtd2d_set_source_extent(self._h, int(nrows), int(ncols)))
+        return self
+
     def run(self, nsteps, src_row=0, src_col=0, amps=None):
         """nsteps of H -> E -> source (python-src/fdtd.py:30-34), asynchronous.
         amps: float64 amplitude per step (None = no source)."""

@@ -320,7 +320,9 @@ def run_fdtd_distributed(rows, cols, dt, dx, nsteps, eps, mu, source, boundary, 
     runner.set_materials(sl(eps), sl(mu))
     amps, sr, sc = None, 0, 0
     if source is not None:
-        kind, sr, sc, fc = source
+        kind, sr, sc, fc, *extent = source
+        if extent:
+            runner.engine.set_source_extent(*extent[0])
         sr = rows // 2 if sr is None else sr
         sc = cols // 2 if sc is None else sc
         f = {"ricker": ricker_amplitude, "sinusoidal": sinusoidal_amplitude}[kind]

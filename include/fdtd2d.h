@@ -165,6 +165,12 @@ int fdtd2d_update_e(fdtd2d_t *h);
  * round(float64(Ez[row,col]) + amp).  A cell outside this handle's rows is ignored. */
 int fdtd2d_add_point(fdtd2d_t *h, int row, int col, double amp);
 
+/* Line / patch sources (the reference's FDTD only has the one-cell source):
+ * from now on the source of fdtd2d_add_point / fdtd2d_run* / fdtd2d_pass_rows is the rectangle of
+ * nrows x ncols cells whose first cell is the (row, col) given there; every cell gets the same
+ * amplitude, rounded per cell like the one-cell source.  Default 1 x 1. */
+int fdtd2d_set_source_extent(fdtd2d_t *h, int nrows, int ncols);
+
 /* The loop of fdtd.py:30-34 for nsteps steps: H, E, source.  amps = nsteps float64
  * amplitudes (host) or NULL for no source.  Asynchronous.  For a slab with
  * neighbours, nsteps must not exceed the halo validity left. */

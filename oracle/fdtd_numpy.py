@@ -160,8 +160,20 @@ def add_point(Ez, row, col, amp):
     return Ez
 
 
+def add_source(Ez, row, col, amp, extent=(1, 1)):
+    """`Ez += s` for a dense s that is `amp` on the rectangle of `extent` = (rows, cols) cells
+    starting at (row, col) and 0 elsewhere: the line / patch source of SURVEY.md 8(f) N3.  The
+    reference only builds the one-cell s (main.py:185-186); with more cells the in-place add
+    rounds each of them exactly as it rounds that one."""
+    nr, nc = extent
+    blk = Ez[row:row + nr, col:col + nc]
+    assert blk.shape == (nr, nc), "source rectangle outside the grid"
+    blk[...] = (blk.astype(np.float64) + np.float64(amp)).astype(Ez.dtype)
+    return Ez
+
+
 def leapfrog(Ez, Hx, Hy, eps, mu, dt, dx, nsteps, src_row, src_col, amps=None,
-             fc=30e9, step0=0, on_step=None):
+             fc=30e9, step0=0, on_step=None, extent=(1, 1)):
     """The loop of fdtd.py:30-34: H, then E (A-D), then the point source.
 
     ``amps`` (float64, one per step) overrides the ricker waveform so that a
@@ -172,7 +184,10 @@ def leapfrog(Ez, Hx, Hy, eps, mu, dt, dx, nsteps, src_row, src_col, amps=None,
         update_h(Ez, Hx, Hy, mu, eps, dt, dx)
         update_e(Ez, Hx, Hy, mu, eps, dt, dx)
         a = amps[n] if amps is not None else ricker_amplitude(i * dt, fc)
-        add_point(Ez, src_row, src_col, a)
+        if tuple(extent) == (1, 1):
+            add_point(Ez, src_row, src_col, a)
+        else:
+            add_source(Ez, src_row, src_col, a, extent)
         if on_step is not None:
             on_step(i, Ez, Hx, Hy)
     return Ez, Hx, Hy

@@ -43,6 +43,8 @@ def worker(rank, world, port, job, outdir):
             runner.set_materials(float(st["eps"][0, 0]), float(st["mu"][0, 0]))
         else:
             runner.set_materials(st["eps"][lo:hi].astype(dtype), st["mu"][lo:hi].astype(dtype))
+        if job.get("extent"):
+            runner.engine.set_source_extent(*job["extent"])
         if job.get("options"):
             runner.engine.set_option(**job["options"])
             assert runner.engine.cycle_steps == job["options"].get("max_pass_steps", 8)

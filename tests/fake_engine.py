@@ -157,6 +157,10 @@ class FakeEngine:
         self.valid = [self.row0, self.row0 + self.nrows]
         self.pending = None
 
+    def set_source_extent(self, nrows=1, ncols=1):
+        self.extent = (int(nrows), int(ncols))
+        return self
+
     def run(self, nsteps, src_row=0, src_col=0, amps=None):
         lo = 0 if self.row0 == 0 else self.valid[0]
         hi = self.rows if self.row0 + self.nrows == self.rows else self.valid[1]
@@ -169,6 +173,8 @@ class FakeEngine:
             onp.update_e(self.Ez, self.Hx, self.Hy, self.mu, self.eps, self.dt, self.dx)
             if amps is not None:
                 slo, shi = self.stored_rows
-                if slo <= src_row < shi:
-                    onp.add_point(self.Ez, src_row, src_col, a[n])
+                nr, nc = getattr(self, "extent", (1, 1))
+                r0, r1 = max(src_row, slo), min(src_row + nr, shi)
+                if r0 < r1:
+                    onp.add_source(self.Ez, r0, src_col, a[n], (r1 - r0, nc))
         self.valid = [self.row0, self.row0 + self.nrows]

@@ -364,6 +364,62 @@ def test_blocked_passes_2048_vs_c_oracle(fd, onp, corc):
         assert np.array_equal(a, b), k
 
 
+@pytest.mark.parametrize("tag,dtype", DTYPES)
+@pytest.mark.parametrize("src,extent", [((40, 3), (1, 420)),      # row line across strips and both side bands
+                                         ((0, 250), (130, 1)),     # column line through both zones
+                                         ((2, 1), (9, 9)),         # patch on the corner block
+                                         ((60, 236), (30, 40)),    # patch over a strip seam
+                                         ((118, 0), (12, 470))])   # bottom zone, full width
+@pytest.mark.parametrize("max_steps", [0, 8, 16])
+def test_line_and_patch_sources_match_oracle(fd, onp, tag, dtype, src, extent, max_steps):
+    """N3: the same amplitude on every cell of a rectangle (row / column lines, patches) --
+    through the half-step kernels (max_steps 0), 8-step and 16-step passes, array eps."""
+    r, c, n = 130, 470, 21
+    if max_steps == 16 and dtype != np.float32:
+        pytest.skip("16-step passes are float32")
+    rng = np.random.default_rng(src[0] * 1000 + src[1])
+    Ez, Hx, Hy, eps, mu = _random_state(rng, r, c, dtype, onp)
+    amps = rng.standard_normal(n)
+    ref = [a.copy() for a in (Ez, Hx, Hy)]
+    onp.leapfrog(*ref, eps, mu, DT, DX, n, src[0], src[1], amps=amps, extent=extent)
+    with fd.Engine(r, c, DT, DX, dtype=dtype) as eng:
+        eng.set_materials(eps, mu).set_option(max_pass_steps=max_steps).set_source_extent(*extent)
+        eng.upload(Ez, Hx, Hy)
+        eng.run(n, src[0], src[1], amps)
+        got = eng.download()
+        with pytest.raises(fd.Fdtd2dError):
+            eng.run(1, r - extent[0] + 1, src[1], amps)          # rectangle leaves the grid
+    for a, b, k in zip(got, ref, ("Ez", "Hx", "Hy")):
+        assert np.array_equal(a, b), f"{k} src={src} extent={extent} {tag}: {np.argwhere(a != b)[:4]}"
+
+
+@pytest.mark.parametrize("shape,kind,max_steps", [((2500, 2300), "uniform", 16), ((2300, 2100), "eps", 16),
+                                                  ((2200, 2050), "eps", 8), ((2048, 2304), "uniform", 8)])
+def test_measured_launch_shapes_vs_c_oracle(fd, onp, corc, shape, kind, max_steps):
+    """Grids above the tuner's 4 Mi-cell threshold: the first pass of each length runs the
+    trial launches of tune_pass() (uncommitted, into the buffers the next pass overwrites) and
+    the run continues with whatever shape measured fastest.  57 steps = 16+16+16+8+1 (or
+    7 x 8 + 1) from a random state must still equal the C oracle bit for bit."""
+    r, c = shape
+    rng = np.random.default_rng(r + c)
+    Ez, Hx, Hy, eps, mu = _random_state(rng, r, c, np.float32, onp)
+    if kind == "uniform":
+        eps = np.full((r, c), 2.5 * onp.EPS0, np.float32)
+    n = 57
+    amps = rng.standard_normal(n)
+    sr, sc = r // 3, c - 7
+    ref = [a.copy() for a in (Ez, Hx, Hy)]
+    corc.run(*ref, eps, mu, DT, DX, n, sr, sc, amps=amps)
+    with fd.Engine(r, c, DT, DX, dtype=np.float32) as eng:
+        eng.set_materials(eps, mu).set_option(max_pass_steps=max_steps)
+        eng.upload(Ez, Hx, Hy)
+        eng.run(n, sr, sc, amps)
+        got = eng.download()
+        assert eng.info(16) == (5 if max_steps == 16 else 8)     # trial launches are not counted
+    for a, b, k in zip(got, ref, ("Ez", "Hx", "Hy")):
+        assert np.array_equal(a, b), f"{k} {shape} {kind}: {np.argwhere(a != b)[:4]}"
+
+
 @pytest.mark.parametrize("cols", [225, 229, 231, 232, 233, 236, 240, 241, 247, 336, 343, 344, 350, 460])
 def test_f64_passes_strip_seams_vs_right_band(fd, onp, cols):
     """float64 is the sharp test for dependency-cone mistakes (in float32 a wrong input ten

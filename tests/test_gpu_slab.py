@@ -25,6 +25,8 @@ DT, DX = 5e-14, 1e-4
     (3, (300, 1100), "float32", "uniform", True, {"max_pass_steps": 16}),
     (2, (160, 700), "float32", "uniform", False, {"max_pass_steps": 16}),
     (2, (170, 600), "float32", "array", True, {"max_pass_steps": 16}),
+    (2, (170, 600), "float32", "array", True, {"max_pass_steps": 16, "extent": (60, 3)}),
+    (3, (180, 520), "float64", "array", True, {"extent": (1, 300)}),
 ])
 def test_gpu_slabs_match_single_engine_and_oracle(tmp_path, world, shape, dtype, materials, overlap,
                                                   options):
@@ -41,19 +43,23 @@ def test_gpu_slabs_match_single_engine_and_oracle(tmp_path, world, shape, dtype,
         st["eps"][:] = 3 * onp.EPS0
     path = os.path.join(str(tmp_path), "state.npz")
     np.savez(path, **st)
-    src = (r // world, c // 2)               # on the first cut
+    extent = (options or {}).get("extent") or (1, 1)
+    src = (r // world, c // 2 - extent[1] // 2)       # on the first cut
     job = dict(engine="hip", shape=shape, dtype=dtype, dt=DT, dx=DX, state=path, src=src,
-               chunks=[n], materials=materials, overlap=overlap, options=options)
+               chunks=[n], materials=materials, overlap=overlap,
+               options={k: v for k, v in (options or {}).items() if k != "extent"} or None,
+               extent=(options or {}).get("extent"))
     got = run_job(world, job, str(tmp_path))
     dt_ = np.dtype(dtype)
     with fd.Engine(r, c, DT, DX, dtype=dt_) as eng:
         eng.set_materials(st["eps"].astype(dt_), st["mu"].astype(dt_))
         eng.upload(st["Ez"].astype(dt_), st["Hx"].astype(dt_), st["Hy"].astype(dt_))
+        eng.set_source_extent(*extent)
         eng.run(n, src[0], src[1], st["amps"])
         one = eng.download()
     ref = [st[k].astype(dt_) for k in ("Ez", "Hx", "Hy")]
     onp.leapfrog(*ref, st["eps"].astype(dt_), st["mu"].astype(dt_), DT, DX, n, src[0], src[1],
-                 amps=st["amps"])
+                 amps=st["amps"], extent=extent)
     for a, b, c_, k in zip(got, one, ref, ("Ez", "Hx", "Hy")):
         assert np.array_equal(a, b), f"{k}: slabs differ from the single engine"
         assert np.array_equal(a, c_), f"{k}: slabs differ from the oracle"

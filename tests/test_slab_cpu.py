@@ -74,6 +74,20 @@ def test_slab_runner_16_row_halo(tmp_path, cycle, overlap):
         assert np.array_equal(a, b), k
 
 
+def test_slab_runner_line_source_across_cut(tmp_path):
+    """A column line source that crosses the cut between two slabs (and their halos)."""
+    r, c = 48, 22
+    st, path = _state(str(tmp_path), r, c, 9, 19, vary_mu=True)
+    job = dict(engine="fake", shape=(r, c), dtype="float32", dt=DT, dx=DX, state=path,
+               src=(10, 7), chunks=[19], materials="array", extent=(30, 2))
+    got = run_job(2, job, str(tmp_path))
+    ref = [st[k].astype(np.float32) for k in ("Ez", "Hx", "Hy")]
+    onp.leapfrog(*ref, st["eps"].astype(np.float32), st["mu"].astype(np.float32), DT, DX, 19,
+                 10, 7, amps=st["amps"], extent=(30, 2))
+    for a, b in zip(got, ref):
+        assert np.array_equal(a, b)
+
+
 def test_slab_runner_uniform_materials(tmp_path):
     r, c = 48, 22
     st, path = _state(str(tmp_path), r, c, 5, 16)

@@ -18,6 +18,7 @@
 #include "kernels_stream.hpp"
 #include "kernels_pml.hpp"
 #include "kernels_split.hpp"
+#include "kernels_probe.hpp"
 
 using fdtd::Geom;
 
@@ -55,6 +56,11 @@ struct fdtd2d {
     Range ev{0, 0}, hv{0, 0};    // global rows on which Ez / (Hx,Hy) are current
     long long step = 0;
     long long pass_launches = 0, step_launches = 0;
+    // point probe (fdtd2d_set_probe): Ez[probe_row, probe_col] after every step since probe_step0
+    int probe_row = 0, probe_col = 0;
+    long long probe_cap = 0, probe_step0 = 0;
+    double *probe_dev = nullptr;
+    bool probe_pending = false;       // the next launch_pass records this pass's steps
     int src_rows = 1, src_cols = 1;   // extent of the source: (row, col) of run/add_point is its first cell
     // a pass issued in pieces (fdtd2d_pass_rows) and not yet committed
     int pend_nt = 0;

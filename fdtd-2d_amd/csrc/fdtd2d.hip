@@ -264,6 +264,21 @@ int do_update_e(fdtd2d *h)
     return 0;
 }
 
+// the half-step path: Ez[probe] after the step that just finished
+int probe_after_step(fdtd2d *h)
+{
+    const long long idx = h->step - 1 - h->probe_step0;
+    if (!h->probe_cap || idx < 0 || idx >= h->probe_cap || h->probe_row < h->ev.lo || h->probe_row >= h->ev.hi)
+        return 0;
+    const size_t off = fdtd::at(h->geom(), h->probe_row, h->probe_col);
+    if (h->dtype == FDTD2D_F32)
+        hipLaunchKernelGGL((fdtd::k_probe_copy<float>), dim3(1), dim3(1), 0, h->stream, (const float *)h->ez[h->cur], off, h->probe_dev, idx);
+    else
+        hipLaunchKernelGGL((fdtd::k_probe_copy<double>), dim3(1), dim3(1), 0, h->stream, (const double *)h->ez[h->cur], off, h->probe_dev, idx);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
 int do_add_point(fdtd2d *h, int row, int col, double amp)
 {
     if (row < 0 || row + h->src_rows > h->rows || col < 0 || col + h->src_cols > h->cols)
@@ -280,6 +295,8 @@ namespace fdtd_host {
 // Can a pass of nt steps run from the current state?  Fills the row range of the bulk.
 bool pass_geometry(const fdtd2d *h, int nt, int *band_lo, int *band_hi)
 {
+    if (h->probe_cap && (nt == 12 || h->boundary == FDTD2D_BOUNDARY_PML))
+        return false;          // no probe tile for these: the run falls back to shorter passes / single steps
     if (h->boundary == FDTD2D_BOUNDARY_PML) {
         // k_pass_pml: 8-step passes, uniform mu, bands over all rows (no zones)
         if (nt != 8 || nt > h->max_nt || !h->ch_uniform || !h->have_pml) return false;
@@ -557,6 +574,7 @@ void fdtd2d_destroy(fdtd2d_t *h)
             if (p) (void)hipFree(p);
         if (h->scratch) (void)hipFree(h->scratch);
         if (h->trash) (void)hipFree(h->trash);
+        if (h->probe_dev) (void)hipFree(h->probe_dev);
         if (h->side_stream) { (void)hipStreamSynchronize(h->side_stream); (void)hipStreamDestroy(h->side_stream); }
         if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
         if (h->ev_join) (void)hipEventDestroy(h->ev_join);
@@ -748,6 +766,41 @@ int fdtd2d_update_e(fdtd2d_t *h)
     return rc ? rc : do_update_e(h);
 }
 
+int fdtd2d_set_probe(fdtd2d_t *h, int row, int col, long long capacity)
+{
+    if (!h) return FDTD2D_E_ARG;
+    if (capacity < 0 || (capacity > 0 && (row < 0 || row >= h->rows || col < 0 || col >= h->cols)))
+        return fail(h, FDTD2D_E_ARG, "probe cell (%d,%d) outside the %dx%d grid, or negative capacity", row, col, h->rows, h->cols);
+    int rc = use_device(h);
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->probe_dev) { (void)hipFree(h->probe_dev); h->probe_dev = nullptr; }
+    h->probe_cap = 0;
+    if (capacity > 0) {
+        if (hipMalloc((void **)&h->probe_dev, (size_t)capacity * sizeof(double)) != hipSuccess)
+            return fail(h, FDTD2D_E_NOMEM, "hipMalloc of %lld probe samples failed", capacity);
+        HIPCHK(h, hipMemsetAsync(h->probe_dev, 0, (size_t)capacity * sizeof(double), h->stream));
+        h->probe_row = row;
+        h->probe_col = col;
+        h->probe_cap = capacity;
+        h->probe_step0 = h->step;
+    }
+    return 0;
+}
+
+int fdtd2d_read_probe(fdtd2d_t *h, double *out, long long first, long long count)
+{
+    if (!h) return FDTD2D_E_ARG;
+    if (!h->probe_cap) return fail(h, FDTD2D_E_STATE, "no probe is set");
+    if (!out || first < 0 || count < 0 || first + count > h->probe_cap)
+        return fail(h, FDTD2D_E_ARG, "samples [%lld,%lld) outside the probe's capacity %lld", first, first + count, h->probe_cap);
+    int rc = use_device(h);
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (count) HIPCHK(h, hipMemcpy(out, h->probe_dev + first, (size_t)count * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int fdtd2d_set_source_extent(fdtd2d_t *h, int nrows, int ncols)
 {
     if (!h) return FDTD2D_E_ARG;
@@ -849,6 +902,7 @@ int fdtd2d_run(fdtd2d_t *h, int nsteps, int src_row, int src_col, const double *
         if (nt) {
             const double *a = amps ? amps + n : nullptr;
             if ((rc = tune_pass(h, nt, lo, hi, h->top(), h->bottom()))) return rc;
+            h->probe_pending = h->probe_cap > 0;
             rc = h->dtype == FDTD2D_F32
                      ? launch_pass<float>(h, nt, lo, hi, src_row, src_col, a, h->top(), h->bottom(), true, lo, hi)
                      : launch_pass<double>(h, nt, lo, hi, src_row, src_col, a, h->top(), h->bottom(), true, lo, hi);
@@ -859,6 +913,7 @@ int fdtd2d_run(fdtd2d_t *h, int nsteps, int src_row, int src_col, const double *
         if ((rc = do_update_h(h))) return rc;
         if ((rc = do_update_e(h))) return rc;
         if (amps && (rc = do_add_point(h, src_row, src_col, amps[n]))) return rc;
+        if ((rc = probe_after_step(h))) return rc;
         ++n;
     }
     return 0;
@@ -895,6 +950,7 @@ int fdtd2d_pass_rows(fdtd2d_t *h, int nt, int row_lo, int row_hi, int src_row, i
     const bool zt = h->top() && row_lo == 0, zb = h->bottom() && row_hi == h->rows;
     const int b_lo = std::max(row_lo, lo), b_hi = std::min(row_hi, hi);
     if ((rc = tune_pass(h, nt, b_lo, b_hi, zt, zb))) return rc;
+    h->probe_pending = h->probe_cap > 0 && h->pend_nt == 0;      // once per pass: with its first piece
     rc = h->dtype == FDTD2D_F32
              ? launch_pass<float>(h, nt, b_lo, b_hi, src_row, src_col, amps, zt, zb, false, lo, hi)
              : launch_pass<double>(h, nt, b_lo, b_hi, src_row, src_col, amps, zt, zb, false, lo, hi);

@@ -97,6 +97,38 @@ template <class T, int NT> int launch_pass_nt(fdtd2d *h, fdtd::PassParams<T> &p)
     }
 }
 
+template <class T, int NT> int launch_probe_nt(fdtd2d *h, const fdtd::PassParams<T> &p, const fdtd::ProbeParams &q)
+{
+    const dim3 one(1), wg(256);
+    if (h->ce_uniform && h->ch_uniform) hipLaunchKernelGGL((fdtd::k_probe<T, NT, false, false>), one, wg, 0, h->stream, p, q);
+    else if (!h->ce_uniform && h->ch_uniform) hipLaunchKernelGGL((fdtd::k_probe<T, NT, true, false>), one, wg, 0, h->stream, p, q);
+    else if (h->ce_uniform) hipLaunchKernelGGL((fdtd::k_probe<T, NT, false, true>), one, wg, 0, h->stream, p, q);
+    else hipLaunchKernelGGL((fdtd::k_probe<T, NT, true, true>), one, wg, 0, h->stream, p, q);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+// Records the nt steps of the pass described by p, if this handle's current rows hold the
+// probe cell's output (on a slab: the owner and the ranks that keep the row as a halo).
+template <class T> int launch_probe(fdtd2d *h, int nt, const fdtd::PassParams<T> &p)
+{
+    const int a = std::max(h->ev.lo, h->hv.lo), b = std::min(h->ev.hi, h->hv.hi);
+    fdtd::ProbeParams q{h->probe_row, h->probe_col, h->top() ? 0 : a, h->bottom() ? h->rows : b,
+                        h->probe_dev, h->step - h->probe_step0, h->probe_cap};
+    const int out_lo = h->top() ? 0 : a + nt, out_hi = h->bottom() ? h->rows : b - nt;
+    if (q.row < out_lo || q.row >= out_hi || q.base < 0 || q.base >= q.cap) return 0;
+    switch (nt) {
+    case 16:
+        if constexpr (sizeof(T) == 4) return launch_probe_nt<T, 16>(h, p, q);
+        return fail(h, FDTD2D_E_ARG, "16-step passes are float32");
+    case 8: return launch_probe_nt<T, 8>(h, p, q);
+    case 4: return launch_probe_nt<T, 4>(h, p, q);
+    case 2: return launch_probe_nt<T, 2>(h, p, q);
+    case 1: return launch_probe_nt<T, 1>(h, p, q);
+    default: return fail(h, FDTD2D_E_ARG, "no probe kernel for %d-step passes", nt);
+    }
+}
+
 #ifdef FDTD_PASS_LONG_EXTERN   // the 12- and 16-step float32 kernels are built in pass_f32_long.hip
 extern template int launch_pass_nt<float, 16>(fdtd2d *, fdtd::PassParams<float> &);
 extern template int launch_pass_nt<float, 12>(fdtd2d *, fdtd::PassParams<float> &);
@@ -170,6 +202,10 @@ template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, 
     p.src_col1 = amps ? src_col + h->src_cols : NONE;
     for (int s = 0; s < fdtd::STREAM_MAX_NT; ++s) p.amp[s] = (amps && s < nt) ? amps[s] : 0.0;
     int rc;
+    if (h->probe_pending) {     // the probe cell's own cone, recomputed by one extra workgroup
+        h->probe_pending = false;
+        if ((rc = launch_probe<T>(h, nt, p))) return rc;
+    }
     if (h->boundary == FDTD2D_BOUNDARY_PML) {
         p.zone_top = p.zone_bot = 0;
         p.zone_tiles = 0;

@@ -221,6 +221,22 @@ class Engine:
     def add_point(self, row, col, amp):
         self._ck(self._lib.fdtd2d_add_point(self._h, int(row), int(col), float(amp)))
 
+    def set_probe(self, row, col, capacity):
+        """Record Ez[row, col] after every step of the following run() calls (capacity samples,
+        also the steps inside temporally blocked passes); capacity 0 removes the probe."""
+        self._ck(self._lib.fdtd2d_set_probe(self._h, int(row), int(col), int(capacity)))
+        self._probe = (int(capacity), self.step_count)
+        return self
+
+    def read_probe(self, first=0, count=None):
+        """float64 samples [first, first + count) of the probe (waits for the stream)."""
+        if count is None:
+            cap, step0 = getattr(self, "_probe", (0, 0))
+            count = max(0, min(cap, self.step_count - step0) - first)
+        out = np.zeros(int(count), np.float64)
+        self._ck(self._lib.fdtd2d_read_probe(self._h, out.ctypes.data, int(first), int(count)))
+        return out
+
     def set_source_extent(self, nrows=1, ncols=1):
         """Line / patch sources: the source of add_point / run / pass_rows becomes the rectangle
         of nrows x ncols cells starting at the (row, col) given there (default one cell)."""

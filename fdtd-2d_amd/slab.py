@@ -282,6 +282,22 @@ class SlabRunner:
         """This rank's owned rows (Ez, Hx, Hy) as host arrays."""
         return self.engine.download()
 
+    # -- point probe (SURVEY.md 8(f) N4) ---------------------------------------------------------
+    def set_probe(self, row, col, capacity):
+        """Ez[row, col] after every step of the following run() calls; recorded on the rank that
+        owns the row (read it there with read_probe)."""
+        self._probe_owner = self.r0 <= int(row) < self.r1
+        if self._probe_owner or self.world == 1:
+            self.engine.set_probe(row, col, capacity)
+        return self
+
+    def read_probe(self, first=0, count=None):
+        """The samples on the owning rank, None elsewhere."""
+        if not getattr(self, "_probe_owner", self.world == 1):
+            return None
+        with self._on_stream():
+            return self.engine.read_probe(first, count)
+
     def gather(self, dst=0):
         """Full fields on rank `dst` (None elsewhere).  Test/diagnostic helper."""
         parts = self.engine.download()

@@ -171,6 +171,16 @@ int fdtd2d_add_point(fdtd2d_t *h, int row, int col, double amp);
  * amplitude, rounded per cell like the one-cell source.  Default 1 x 1. */
 int fdtd2d_set_source_extent(fdtd2d_t *h, int nrows, int ncols);
 
+/* Point probe: from now on fdtd2d_run* / fdtd2d_pass_rows record
+ * Ez[row, col] after the source of every step -- also the steps inside a temporally blocked pass,
+ * which never reach memory otherwise -- as float64 into a device buffer of `capacity` samples
+ * (sample 0 = the first step after this call; capacity 0 removes the probe).  On a slab only
+ * handles whose current rows hold the cell record it.  fdtd2d_read_probe waits for the stream
+ * and copies samples [first, first + count) to the host.  With the PML boundary a probed run
+ * uses the single-step kernels. */
+int fdtd2d_set_probe(fdtd2d_t *h, int row, int col, long long capacity);
+int fdtd2d_read_probe(fdtd2d_t *h, double *out, long long first, long long count);
+
 /* The loop of fdtd.py:30-34 for nsteps steps: H, E, source.  amps = nsteps float64
  * amplitudes (host) or NULL for no source.  Asynchronous.  For a slab with
  * neighbours, nsteps must not exceed the halo validity left. */

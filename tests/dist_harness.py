@@ -50,10 +50,16 @@ def worker(rank, world, port, job, outdir):
             assert runner.engine.cycle_steps == job["options"].get("max_pass_steps", 8)
         runner.upload(st["Ez"][r0:r1].astype(dtype), st["Hx"][r0:r1].astype(dtype),
                       st["Hy"][r0:min(r1, rows - 1)].astype(dtype))
+        if job.get("probe"):
+            runner.set_probe(job["probe"][0], job["probe"][1], sum(job["chunks"]))
         done = 0
         for n in job["chunks"]:
             runner.run(n, job["src"][0], job["src"][1], st["amps"][done:done + n])
             done += n
+        if job.get("probe"):
+            pr = runner.read_probe()
+            if pr is not None:
+                np.save(os.path.join(outdir, "probe.npy"), pr)
         out = runner.gather(0)
         if rank == 0:
             np.savez(os.path.join(outdir, "result.npz"), Ez=out[0], Hx=out[1], Hy=out[2])

@@ -107,3 +107,42 @@ def test_reference_experiment_script(tmp_path, golden_dir):
     eps, mu = onp.vacuum_materials(64, 72)
     onp.leapfrog(*ref, eps, mu, DT, DX, 40, 32, 36)
     assert np.array_equal(Ez, ref[0]) and np.array_equal(Hx, ref[1])
+
+
+@pytest.mark.parametrize("tag,dtype", [("f32", np.float32), ("f64", np.float64)])
+@pytest.mark.parametrize("probe", [(70, 250), (0, 0), (3, 466), (129, 235), (64, 2), (20, 236), (126, 4)])
+@pytest.mark.parametrize("max_steps", [0, 8, 16])
+def test_probe_time_series_matches_oracle(tag, dtype, probe, max_steps):
+    """N4: Ez at one cell after every step -- interior, corners, side bands, zones, a strip seam --
+    including the steps inside 8- and 16-step passes (recomputed by the probe tile), against
+    the oracle's per-step values; 45 steps with a patch source, array eps."""
+    import fdtd2d_amd as fd
+    from oracle import fdtd_numpy as onp
+    if max_steps == 16 and dtype != np.float32:
+        pytest.skip("16-step passes are float32")
+    r, c, n = 130, 470, 45
+    rng = np.random.default_rng(probe[0] * 7 + probe[1])
+    Ez = rng.standard_normal((r, c)).astype(dtype)
+    Hx = (rng.standard_normal((r, c - 1)) * 1e-3).astype(dtype)
+    Hy = (rng.standard_normal((r - 1, c)) * 1e-3).astype(dtype)
+    eps = (onp.EPS0 * rng.uniform(1, 10, (r, c))).astype(dtype)
+    mu = np.full((r, c), onp.MU0, dtype)
+    amps = rng.standard_normal(n)
+    want = []
+    ref = [a.copy() for a in (Ez, Hx, Hy)]
+    onp.leapfrog(*ref, eps, mu, 5e-14, 1e-4, n, 60, 230, amps=amps, extent=(4, 12),
+                 on_step=lambda i, E, *_: want.append(float(E[probe])))
+    with fd.Engine(r, c, 5e-14, 1e-4, dtype=dtype) as eng:
+        eng.set_materials(eps, mu).set_option(max_pass_steps=max_steps).set_source_extent(4, 12)
+        eng.upload(Ez, Hx, Hy)
+        eng.run(3, 60, 230, amps[:3])                     # the probe starts mid-run
+        eng.set_probe(probe[0], probe[1], n)
+        eng.run(n - 3, 60, 230, amps[3:])
+        got = eng.read_probe()
+        fields = eng.download()
+        assert eng.read_probe(5, 4).tolist() == got[5:9].tolist()
+        with pytest.raises(fd.Fdtd2dError):
+            eng.read_probe(0, n + 1)
+    assert got.shape == (n - 3,) and np.array_equal(got, np.array(want[3:]))
+    for a, b in zip(fields, ref):
+        assert np.array_equal(a, b)

@@ -65,6 +65,31 @@ def test_gpu_slabs_match_single_engine_and_oracle(tmp_path, world, shape, dtype,
         assert np.array_equal(a, c_), f"{k}: slabs differ from the oracle"
 
 
+@pytest.mark.parametrize("probe_row", [85, 84, 100, 2])
+def test_gpu_slabs_probe_next_to_the_cut(tmp_path, probe_row):
+    """N4 over two slabs (cut at row 85): the probe on the first owned row of rank 1, on the
+    last one of rank 0, further inside, and in rank 0's top zone; overlapped 16-step cycles."""
+    from oracle import fdtd_numpy as onp
+    r, c, n = 170, 600, 45
+    rng = np.random.default_rng(probe_row)
+    st = dict(Ez=rng.standard_normal((r, c)), Hx=rng.standard_normal((r, c - 1)) * 1e-3,
+              Hy=rng.standard_normal((r - 1, c)) * 1e-3,
+              eps=onp.EPS0 * rng.uniform(1, 10, (r, c)), mu=onp.MU0 * np.ones((r, c)),
+              amps=rng.standard_normal(n))
+    path = os.path.join(str(tmp_path), "state.npz")
+    np.savez(path, **st)
+    job = dict(engine="hip", shape=(r, c), dtype="float32", dt=DT, dx=DX, state=path, src=(80, 300),
+               chunks=[n], materials="array", overlap=True, options={"max_pass_steps": 16},
+               probe=(probe_row, 301))
+    run_job(2, job, str(tmp_path))
+    got = np.load(os.path.join(str(tmp_path), "probe.npy"))
+    want = []
+    ref = [st[k].astype(np.float32) for k in ("Ez", "Hx", "Hy")]
+    onp.leapfrog(*ref, st["eps"].astype(np.float32), st["mu"].astype(np.float32), DT, DX, n, 80, 300,
+                 amps=st["amps"], on_step=lambda i, E, *_: want.append(float(E[probe_row, 301])))
+    assert np.array_equal(got, np.array(want))
+
+
 def test_gpu_slabs_pml_match_single_engine(tmp_path):
     """boundary="pml" over 2 slabs (4-field halo messages, single-step kernels consuming the
     halo) equals the single-engine PML run bit for bit."""

@@ -115,6 +115,7 @@ def time_single(fd, rows, cols, steps, warmup, materials, device, boundary="mur"
     if boundary == "pml":
         eng.set_pml()
     sr, sc = rows // 2, cols // 2
+    eng.prepare(steps)          # launch-shape tuner (trial launches, state untouched): part of set-up
     eng.run(warmup, sr, sc, amplitudes(fd, 0, warmup)).sync()
     amps = amplitudes(fd, warmup, steps)
     l0 = eng.info(16), eng.info(17)

@@ -878,6 +878,31 @@ static int tune_pass(fdtd2d *h, int nt, int lo, int hi, bool zt, bool zb)
     return rc;
 }
 
+int fdtd2d_prepare(fdtd2d_t *h, int nsteps)
+{
+    int rc = need_ready(h);
+    if (rc) return rc;
+    if (h->pend_nt) return fail(h, FDTD2D_E_STATE, "a partial pass is pending: commit it first");
+    // the pass lengths fdtd2d_run(nsteps) will use from the current state: the long ones are
+    // tuned, the 4/2/1-step tail kernels get one uncommitted launch (code objects loaded)
+    const long long launches = h->pass_launches;
+    int left = nsteps;
+    for (int c : {16, 8, 4, 2, 1}) {
+        int lo = 0, hi = 0;
+        if (c > left || (c == 16 && h->cycle_steps() != 16) || !pass_geometry(h, c, &lo, &hi)) continue;
+        left %= c;
+        if (c >= 8)
+            rc = tune_pass(h, c, lo, hi, h->top(), h->bottom());
+        else
+            rc = h->dtype == FDTD2D_F32
+                     ? launch_pass<float>(h, c, lo, hi, 0, 0, nullptr, h->top(), h->bottom(), false, lo, hi)
+                     : launch_pass<double>(h, c, lo, hi, 0, 0, nullptr, h->top(), h->bottom(), false, lo, hi);
+        if (rc) return rc;
+    }
+    h->pass_launches = launches;
+    return hipStreamSynchronize(h->stream) == hipSuccess ? 0 : fail(h, FDTD2D_E_STATE, "stream sync failed");
+}
+
 int fdtd2d_run(fdtd2d_t *h, int nsteps, int src_row, int src_col, const double *amps)
 {
     int rc = need_ready(h);

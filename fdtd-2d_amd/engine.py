@@ -221,6 +221,12 @@ class Engine:
     def add_point(self, row, col, amp):
         self._ck(self._lib.fdtd2d_add_point(self._h, int(row), int(col), float(amp)))
 
+    def prepare(self, nsteps):
+        """Measure the launch shapes run(nsteps) will use now (trial launches that leave the
+        fields untouched) instead of inside its first passes."""
+        self._ck(self._lib.fdtd2d_prepare(self._h, int(nsteps)))
+        return self
+
     def set_probe(self, row, col, capacity):
         """Record Ez[row, col] after every step of the following run() calls (capacity samples,
         also the steps inside temporally blocked passes); capacity 0 removes the probe."""

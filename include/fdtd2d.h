@@ -186,6 +186,11 @@ int fdtd2d_read_probe(fdtd2d_t *h, double *out, long long first, long long count
  * neighbours, nsteps must not exceed the halo validity left. */
 int fdtd2d_run(fdtd2d_t *h, int nsteps, int src_row, int src_col, const double *amps);
 
+/* Optional: measure the launch shapes fdtd2d_run(nsteps) will use (FDTD2D_OPT_AUTOTUNE) now
+ * instead of inside its first passes.  Blocks for the 20-120 ms of trial launches; the fields
+ * and the step counter are untouched. */
+int fdtd2d_prepare(fdtd2d_t *h, int nsteps);
+
 /* One temporally blocked pass of nt in {1,2,4,8,16} steps issued in pieces, so that a caller can
  * compute the rows its neighbours wait for first, send them, and overlap the transfer with
  * the rest: fdtd2d_pass_rows() launches the pass for output rows [row_lo,row_hi) only (reading

@@ -413,6 +413,9 @@ def test_measured_launch_shapes_vs_c_oracle(fd, onp, corc, shape, kind, max_step
     with fd.Engine(r, c, DT, DX, dtype=np.float32) as eng:
         eng.set_materials(eps, mu).set_option(max_pass_steps=max_steps)
         eng.upload(Ez, Hx, Hy)
+        if kind == "uniform":
+            eng.prepare(n)                                       # tuner ahead of the run: state untouched
+            assert eng.step_count == 0 and eng.info(16) == 0
         eng.run(n, sr, sc, amps)
         got = eng.download()
         assert eng.info(16) == (5 if max_steps == 16 else 8)     # trial launches are not counted

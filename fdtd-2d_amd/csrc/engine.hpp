@@ -173,8 +173,9 @@ bool pass_geometry(const fdtd2d *h, int nt, int *band_lo, int *band_hi);
 // One pass of nt steps (or the rows [band_lo, band_hi) of it); see pass_impl.hpp.
 template <class T>
 int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, int src_row, int src_col,
-                const double *amps, bool ztop, bool zbot, bool commit, int full_lo, int full_hi);
-extern template int launch_pass<float>(fdtd2d *, int, int, int, int, int, const double *, bool, bool, bool, int, int);
-extern template int launch_pass<double>(fdtd2d *, int, int, int, int, int, const double *, bool, bool, bool, int, int);
+                const double *amps, bool ztop, bool zbot, bool commit, int full_lo, int full_hi,
+                int nlev = 0);
+extern template int launch_pass<float>(fdtd2d *, int, int, int, int, int, const double *, bool, bool, bool, int, int, int);
+extern template int launch_pass<double>(fdtd2d *, int, int, int, int, int, const double *, bool, bool, bool, int, int, int);
 
 }  // namespace fdtd_host

@@ -915,6 +915,24 @@ int fdtd2d_run(fdtd2d_t *h, int nsteps, int src_row, int src_col, const double *
                     h->src_rows, h->src_cols, h->rows, h->cols);
     int n = 0;
     while (n < nsteps) {
+        // a tail that is not a power of two: ONE short pass on the longest kernel (each pass is a
+        // full sweep over the grid, whatever its length)
+        {
+            const int rem = nsteps - n, L = h->cycle_steps();
+            int lo = 0, hi = 0;
+            if (L >= 8 && rem < L && (rem & (rem - 1)) != 0 && pass_geometry(h, L, &lo, &hi) &&
+                h->use_level_split(L, lo, hi)) {
+                if ((rc = tune_pass(h, L, lo, hi, h->top(), h->bottom()))) return rc;
+                h->probe_pending = h->probe_cap > 0;
+                const double *a = amps ? amps + n : nullptr;
+                rc = h->dtype == FDTD2D_F32
+                         ? launch_pass<float>(h, L, lo, hi, src_row, src_col, a, h->top(), h->bottom(), true, lo, hi, rem)
+                         : launch_pass<double>(h, L, lo, hi, src_row, src_col, a, h->top(), h->bottom(), true, lo, hi, rem);
+                if (rc) return rc;
+                n += rem;
+                continue;
+            }
+        }
         // longest temporally blocked pass that fits, else one plain step
         int nt = 0, lo = 0, hi = 0;
         for (int c : {16, 12, 8, 4, 2, 1})

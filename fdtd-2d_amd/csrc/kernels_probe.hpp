@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void k_probe(const PassParams<T> p, const Prob
     __syncthreads();
     int cur = 0;
 #pragma unroll 1
-    for (int step = 1; step <= NT; ++step) {
+    for (int step = 1; step <= p.nlev; ++step) {
         const T *Eo = smem + cur * ZS;
         T *En = smem + (cur ^ 1) * ZS;
         for (int n = threadIdx.x; n < cells; n += 256) {          // H half-step (main.py:66-76)

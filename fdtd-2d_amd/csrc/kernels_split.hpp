@@ -189,7 +189,7 @@ __device__ __forceinline__ void split_body(const PassParams<T> &p, const int str
 #pragma unroll
             for (int l = 1; l <= LV; ++l) {
                 const int t = t0 + l, i = r - l;
-                if (i < ra - (NT - t) - 1 || i >= rb + (NT - t)) continue;      // outside the cone
+                if (i < ra - (NT - t) - 1 || i >= rb + (NT - t) || t > p.nlev) continue;   // outside the cone / a short pass
                 Row &c = slot[(k - l + 2 * S) % S];
                 m.level(c, slot[(k - l + 1 + 2 * S) % S].e, slot[(k - l - 1 + 2 * S) % S].x, t, i);
             }

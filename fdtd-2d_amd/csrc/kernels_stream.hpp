@@ -60,6 +60,8 @@ template <class T> struct PassParams {
     T *trash;                  // >= 3 x 1 KiB of device scratch: where masked-off stores land
     int src_row, src_col;      // first source cell; the source is the rectangle
     int src_row1, src_col1;    // [src_row, src_row1) x [src_col, src_col1) (all four very negative: none)
+    int nlev;                  // time levels this launch really advances (<= NT; the level-split
+                               // kernel, the zone tiles and the probe tile skip the rest)
     double amp[STREAM_MAX_NT]; // amplitude added after step s = 1..NT of this pass
 };
 
@@ -367,7 +369,7 @@ __device__ __forceinline__ void zone_body(const PassParams<T> &p, const int tile
 
     int cur = 0;
 #pragma unroll 1
-    for (int step = 1; step <= NT; ++step) {
+    for (int step = 1; step <= p.nlev; ++step) {
         const T *Eo = smem + cur * ZS;
         T *En = smem + (cur ^ 1) * ZS;
         // H half-step (main.py:66-76) on every cell whose i+1 / j+1 neighbours are in the tile

@@ -3,5 +3,5 @@
 #define FDTD_PASS_LONG_EXTERN
 #include "pass_impl.hpp"
 namespace fdtd_host {
-template int launch_pass<float>(fdtd2d *, int, int, int, int, int, const double *, bool, bool, bool, int, int);
+template int launch_pass<float>(fdtd2d *, int, int, int, int, int, const double *, bool, bool, bool, int, int, int);
 }

@@ -137,7 +137,7 @@ extern template int launch_pass_nt<float, 12>(fdtd2d *, fdtd::PassParams<float> 
 // One pass of nt in {1,2,4,8,16} steps; amps = nt amplitudes or nullptr.
 template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, int src_row,
                                    int src_col, const double *amps, bool ztop, bool zbot,
-                                   bool commit, int full_lo, int full_hi)
+                                   bool commit, int full_lo, int full_hi, int nlev)
 {
     // (k_bulk also instantiates with 2 columns per lane -- 86 VGPRs, 4-5 waves per SIMD -- but
     // that measured 20 % slower than 4 columns: profiles/r01_kpass_ablation.txt)
@@ -200,7 +200,12 @@ template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, 
     p.src_col = amps ? src_col : NONE;
     p.src_row1 = amps ? src_row + h->src_rows : NONE;
     p.src_col1 = amps ? src_col + h->src_cols : NONE;
-    for (int s = 0; s < fdtd::STREAM_MAX_NT; ++s) p.amp[s] = (amps && s < nt) ? amps[s] : 0.0;
+    // a short pass: the nt-step kernel and geometry, advancing only nlev < nt levels (one sweep
+    // over the grid for a tail of 3, 5, 6, 7, 9..15 steps instead of one per power of two)
+    p.nlev = nlev > 0 ? std::min(nlev, nt) : nt;
+    if (p.nlev != nt && !h->use_level_split(nt, band_lo, band_hi))
+        return fail(h, FDTD2D_E_ARG, "short passes run on the level-split kernel only");
+    for (int s = 0; s < fdtd::STREAM_MAX_NT; ++s) p.amp[s] = (amps && s < p.nlev) ? amps[s] : 0.0;
     int rc;
     if (h->probe_pending) {     // the probe cell's own cone, recomputed by one extra workgroup
         h->probe_pending = false;
@@ -253,7 +258,7 @@ template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, 
         h->cur ^= 1;
         h->hcur ^= 1;
         h->ev = h->hv = Range{h->top() ? 0 : full_lo, h->bottom() ? h->rows : full_hi};
-        h->step += nt;
+        h->step += p.nlev;
     }
     return 0;
 }

@@ -123,7 +123,10 @@ __device__ __forceinline__ void split_body(const PassParams<T> &p, const int str
     constexpr int LV = NT / SPLIT_NW, LAG = LV + 1;
     constexpr int HC = stream_hc(NT);
     constexpr int SW = 64 * V, OW = SW - 2 * HC;
-    constexpr int PF = ROLE == 0 ? 2 : 0;       // only the first wave hides HBM latency
+#ifndef SPLIT_PF
+#define SPLIT_PF 2
+#endif
+    constexpr int PF = ROLE == 0 ? SPLIT_PF : 0;       // only the first wave hides HBM latency
     constexpr int S = LV + 2 + PF;              // ring of row slots, tick loop unrolled S times
     const Geom g = p.g;
     const int lane = threadIdx.x & 63;

@@ -918,7 +918,10 @@ int fdtd2d_run(fdtd2d_t *h, int nsteps, int src_row, int src_col, const double *
         // a tail that is not a power of two: ONE short pass on the longest kernel (each pass is a
         // full sweep over the grid, whatever its length)
         {
-            const int rem = nsteps - n, L = h->cycle_steps();
+            // (the levels are not re-balanced over the waves of a strip, so a short pass costs
+            // about a full pass of its kernel: tails below 8 take the 8-step kernel,
+            // profiles/r01_short_pass_cost.txt)
+            const int rem = nsteps - n, L = (h->cycle_steps() == 16 && rem < 8) ? 8 : h->cycle_steps();
             int lo = 0, hi = 0;
             if (L >= 8 && rem < L && (rem & (rem - 1)) != 0 && pass_geometry(h, L, &lo, &hi) &&
                 h->use_level_split(L, lo, hi)) {

@@ -581,7 +581,7 @@ def test_short_tail_passes_match_oracle(fd, onp, tag, dtype, n, kind):
         eng.run(n, 1, 236, amps)
         got = eng.download()
         series = eng.read_probe()
-        assert eng.step_count == n and eng.info(16) == n // L + (1 if n % L else 0)
+        assert eng.step_count == n and eng.info(16) == n // L + (1 if n % L else 0)    # full passes + one tail
     for a, b, k in zip(got, ref, ("Ez", "Hx", "Hy")):
         assert np.array_equal(a, b), f"{k} n={n} {kind} {tag}: {np.argwhere(a != b)[:4]}"
     assert np.array_equal(series, np.array(want))

@@ -105,6 +105,7 @@ struct fdtd2d {
     };
     std::map<std::array<int, 3>, Shape> tuned;
     int autotune = 1;            // FDTD2D_OPT_AUTOTUNE / FDTD2D_AUTOTUNE=0
+    int xcd_map = 0;             // FDTD2D_XCD_MAP: XCD-aware order of the strips in k_bulk_split
     Shape shape_now{0, 0};       // shape of the launch being issued (set by launch_pass)
     Shape shape_last{0, 0};      // band height / waves per strip actually used by the last pass
     int split_waves = 0;         // waves per strip in k_bulk_split: 0 = automatic, 4 or 8

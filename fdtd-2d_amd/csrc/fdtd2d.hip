@@ -450,6 +450,7 @@ int create_impl(fdtd2d_t **out, int rows, int cols, int row0, int nrows, int hal
     }
     if (const char *e2 = std::getenv("FDTD2D_BAND_ROWS")) h->stream_band_rows = std::atoi(e2);
     if (const char *e3 = std::getenv("FDTD2D_AUTOTUNE")) h->autotune = std::atoi(e3) != 0;
+    if (const char *e4 = std::getenv("FDTD2D_XCD_MAP")) h->xcd_map = std::atoi(e4) != 0;
     if (const char *e2 = std::getenv("FDTD2D_MAX_NT")) { h->max_nt = std::atoi(e2); h->max_nt_forced = true; }
     if (const char *e2 = std::getenv("FDTD2D_EDGE_DIV")) h->edge_band_div = std::max(1, std::atoi(e2));
     if (const char *e2 = std::getenv("FDTD2D_ZONE_SPLIT")) h->zone_split = std::atoi(e2);

@@ -252,7 +252,20 @@ __global__ __launch_bounds__(64 * SPLIT_NW) void k_bulk_split(const PassParams<T
         rb = min(ra + p.band_rows_e, p.band_hi);
     } else {
         b -= 2 * p.nbands_e;
-        const int sidx = b / p.nbands, band = b - sidx * p.nbands;
+        int sidx, band;
+        if (p.xcd_map) {
+            // Workgroups go to the 8 XCDs round-robin.  Give XCD x the bands x, x+8, ... and make
+            // the strips of one band consecutive on it: neighbouring strips read the same rows at
+            // the same time, so the cache lines they share (the 32 overlap columns straddle two)
+            // are fetched from HBM once per XCD L2 instead of once per strip.
+            const int inner = p.nstrips - 2, x = b & 7, y = b >> 3, bl = y / inner;
+            sidx = y - bl * inner;
+            band = bl * 8 + x;
+            if (band >= p.nbands) return;
+        } else {
+            sidx = b / p.nbands;
+            band = b - sidx * p.nbands;
+        }
         strip = sidx + 1;
         ra = p.band_lo + band * p.band_rows;
         rb = min(ra + p.band_rows, p.band_hi);

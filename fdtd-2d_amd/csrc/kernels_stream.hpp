@@ -60,6 +60,7 @@ template <class T> struct PassParams {
     T *trash;                  // >= 3 x 1 KiB of device scratch: where masked-off stores land
     int src_row, src_col;      // first source cell; the source is the rectangle
     int src_row1, src_col1;    // [src_row, src_row1) x [src_col, src_col1) (all four very negative: none)
+    int xcd_map;               // k_bulk_split: strips of one band are consecutive workgroups of one XCD
     int nlev;                  // time levels this launch really advances (<= NT; the level-split
                                // kernel, the zone tiles and the probe tile skip the rest)
     double amp[STREAM_MAX_NT]; // amplitude added after step s = 1..NT of this pass

@@ -16,7 +16,9 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
     p.zone_tiles = (h->cols + D::WZ - 1) / D::WZ;
     // launch order: zone tiles, 2 edge-strip slots (the second stays empty with one strip),
     // then strips 1 .. nstrips-2
-    const long long bulk = 2LL * p.nbands_e + (long long)p.nbands * std::max(0, p.nstrips - 2);
+    p.xcd_map = h->xcd_map && (NT == 16 || NT == 8) && h->use_level_split(NT, p.band_lo, p.band_hi) && p.nstrips > 2;
+    const long long bulk = 2LL * p.nbands_e + (long long)(p.xcd_map ? (p.nbands + 7) / 8 * 8 : p.nbands) *
+                                                  std::max(0, p.nstrips - 2);
     const long long zones = (long long)(p.zone_top + p.zone_bot) * p.zone_tiles;
     if (bulk + zones == 0) return 0;
     if constexpr (NT == 16 || NT == 8) {

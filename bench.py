@@ -265,6 +265,7 @@ def main():
         runner.run(max(args.warmup, 32), sr, sc, amplitudes(fd, 0, max(args.warmup, 32)))
     amps = amplitudes(fd, args.warmup, args.steps)
     cycle = min(runner.halo, runner.engine.cycle_steps or runner.halo)   # steps per exchange
+    runner.prepare(args.steps)      # kernels of the last, shorter cycle: part of set-up
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()

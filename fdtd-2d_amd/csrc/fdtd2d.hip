@@ -884,22 +884,34 @@ int fdtd2d_prepare(fdtd2d_t *h, int nsteps)
     int rc = need_ready(h);
     if (rc) return rc;
     if (h->pend_nt) return fail(h, FDTD2D_E_STATE, "a partial pass is pending: commit it first");
-    // the pass lengths fdtd2d_run(nsteps) will use from the current state: the long ones are
-    // tuned, the 4/2/1-step tail kernels get one uncommitted launch (code objects loaded)
+    // the pass lengths fdtd2d_run(nsteps) will use from the current state (same decisions as its
+    // loop): the long ones are tuned, tail kernels get one uncommitted launch (code objects loaded)
     const long long launches = h->pass_launches;
+    auto warm = [&](int c, int lo, int hi, int nlev) {
+        return h->dtype == FDTD2D_F32
+                   ? launch_pass<float>(h, c, lo, hi, 0, 0, nullptr, h->top(), h->bottom(), false, lo, hi, nlev)
+                   : launch_pass<double>(h, c, lo, hi, 0, 0, nullptr, h->top(), h->bottom(), false, lo, hi, nlev);
+    };
     int left = nsteps;
-    for (int c : {16, 8, 4, 2, 1}) {
+    while (left > 0 && rc == 0) {
         int lo = 0, hi = 0;
-        if (c > left || (c == 16 && h->cycle_steps() != 16) || !pass_geometry(h, c, &lo, &hi)) continue;
-        left %= c;
-        if (c >= 8)
-            rc = tune_pass(h, c, lo, hi, h->top(), h->bottom());
-        else
-            rc = h->dtype == FDTD2D_F32
-                     ? launch_pass<float>(h, c, lo, hi, 0, 0, nullptr, h->top(), h->bottom(), false, lo, hi)
-                     : launch_pass<double>(h, c, lo, hi, 0, 0, nullptr, h->top(), h->bottom(), false, lo, hi);
-        if (rc) return rc;
+        const int L = (h->cycle_steps() == 16 && left < 8) ? 8 : h->cycle_steps();
+        if (L >= 8 && left < L && (left & (left - 1)) != 0 && pass_geometry(h, L, &lo, &hi) &&
+            h->use_level_split(L, lo, hi)) {
+            rc = warm(L, lo, hi, left);                     // the short tail pass
+            break;
+        }
+        int nt = 0;
+        for (int c : {16, 8, 4, 2, 1})
+            if (c <= left && (c != 16 || h->cycle_steps() == 16) && pass_geometry(h, c, &lo, &hi)) {
+                nt = c;
+                break;
+            }
+        if (!nt) break;                                     // single-step kernels: nothing to prepare
+        rc = nt >= 8 ? tune_pass(h, nt, lo, hi, h->top(), h->bottom()) : warm(nt, lo, hi, 0);
+        left %= nt;
     }
+    if (rc) return rc;
     h->pass_launches = launches;
     return hipStreamSynchronize(h->stream) == hipSuccess ? 0 : fail(h, FDTD2D_E_STATE, "stream sync failed");
 }
@@ -926,7 +938,8 @@ int fdtd2d_run(fdtd2d_t *h, int nsteps, int src_row, int src_col, const double *
             int lo = 0, hi = 0;
             if (L >= 8 && rem < L && (rem & (rem - 1)) != 0 && pass_geometry(h, L, &lo, &hi) &&
                 h->use_level_split(L, lo, hi)) {
-                if ((rc = tune_pass(h, L, lo, hi, h->top(), h->bottom()))) return rc;
+                // (no tune_pass here: a one-off tail does not pay for 20-120 ms of trial launches;
+                // the shape measured for full passes of this length is used if there is one)
                 h->probe_pending = h->probe_cap > 0;
                 const double *a = amps ? amps + n : nullptr;
                 rc = h->dtype == FDTD2D_F32

@@ -282,6 +282,21 @@ class SlabRunner:
         """This rank's owned rows (Ez, Hx, Hy) as host arrays."""
         return self.engine.download()
 
+    def prepare(self, nsteps):
+        """Tune / warm the kernels of the LAST, shorter cycle of run(nsteps) now (the full cycles
+        are tuned by the first cycles of a run or of a warm-up).  Leaves the fields untouched."""
+        prep = getattr(self.engine, "prepare", None)
+        if prep is None:
+            return self
+        cycle = min(self.halo, getattr(self.engine, "cycle_steps", self.halo) or self.halo) if self.world > 1 else 0
+        tail = nsteps % cycle if cycle else nsteps
+        with self._on_stream():
+            if self.world > 1 and not self._halo_fresh:
+                self.exchange()
+            if tail:
+                prep(tail)
+        return self
+
     # -- point probe (SURVEY.md 8(f) N4) ---------------------------------------------------------
     def set_probe(self, row, col, capacity):
         """Ez[row, col] after every step of the following run() calls; recorded on the rank that

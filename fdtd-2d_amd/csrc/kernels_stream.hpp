@@ -373,8 +373,13 @@ __device__ __forceinline__ void zone_body(const PassParams<T> &p, const int tile
     for (int step = 1; step <= p.nlev; ++step) {
         const T *Eo = smem + cur * ZS;
         T *En = smem + (cur ^ 1) * ZS;
+        // Rows still inside the cone of the ZO output rows: with k steps to go after this one,
+        // level `step` is needed on the ZO + k rows next to the grid edge (the Mur rows grow two
+        // rows per step, 4 + 2 k + 2 <= ZO + k + 2); one row more for the H of the next step.
+        const int keep = min(D::ZR, D::ZO + (p.nlev - step) + 2);
+        const int r_lo = bottom ? D::ZR - keep : 0, r_hi = bottom ? D::ZR : keep;
         // H half-step (main.py:66-76) on every cell whose i+1 / j+1 neighbours are in the tile
-        for (int li = lr; li < D::ZR; li += RG) {
+        for (int li = r_lo + lr; li < r_hi; li += RG) {
             const int i = z0 + li;
             if (col_ok && i <= g.R - 2 && j <= g.C - 2 && li + 1 < D::ZR && lj + 1 < wl) {
                 const int s = li * D::WLP + lj;
@@ -388,7 +393,7 @@ __device__ __forceinline__ void zone_body(const PassParams<T> &p, const int tile
         // E half-step: stages A-D as one pure function of (Eo, new H) per cell; plain interior
         // cells (the vast majority) take the direct formula
         MurRules<T, TileAcc<T, CE_ARR>> rules{{Eo, sX, sY, p.ce, p.ce_u, g, g.R, g.C, z0, c0, D::WLP}, p.k};
-        for (int li = lr; li < D::ZR; li += RG) {
+        for (int li = r_lo + lr; li < r_hi; li += RG) {
             const int i = z0 + li;
             const int s = li * D::WLP + lj;
             if (col_ok) {

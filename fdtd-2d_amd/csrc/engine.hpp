@@ -112,11 +112,13 @@ struct fdtd2d {
     int split_waves_for(int nt, int lo, int hi) const
     {
         if (!split_waves && shape_now.waves) return shape_now.waves;
-        // 4 waves x NT/4 levels.  8 x NT/8 was 10 % faster at 4096^2 while the zone tiles ran as
-        // their own kernel (profiles/r01_split_waves_sweep.txt); with the tiles fused into the
-        // launch the tuner keeps picking 4, and 8 stays one of its candidates.
-        (void)nt, (void)lo, (void)hi;
-        return split_waves ? split_waves : 4;
+        // 4 waves x NT/4 levels on large slabs (what the tuner keeps picking from 4096^2 up); 8 waves
+        // x NT/8 levels shorten the tick chain that bounds small ones: 8-step passes 27.8 vs 33.7 us
+        // at 512^2, 31 vs 37 at 1024^2, equal at 2048^2, 63 vs 49 at 3072^2; 16-step passes 38 vs 56
+        // at 2048^2, 57 vs 59 at 3072^2, 87 vs 78 at 4096^2 (profiles/r01_split_waves_sweep.txt)
+        if (split_waves) return split_waves;
+        const size_t cells = (size_t)std::max(0, hi - lo) * cols;
+        return cells < (nt == 16 ? (size_t)12 << 20 : (size_t)3 << 20) ? 8 : 4;
     }
     bool max_nt_forced = false;  // set_option(MAX_PASS_STEPS): no size rule for 16-step passes
     int cycle_steps() const      // longest pass this configuration runs

@@ -13,7 +13,7 @@ def t(e, n):
         best = min(best, ms / (n / 8) * 1000)
     return best
 
-for g in (1024, 2048, 3072, 4096, 6144, 8192):
+for g in (512, 1024, 2048, 3072, 4096):
     with fd.Engine(g, g, dtype=np.float32) as e:
         e.set_materials(); e.run(32); e.sync()
         n = 320

@@ -299,7 +299,7 @@ def main():
                        "exchange": exchange_mode},
             "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS * world,
                          "unit": "GB/s", "frac": round(ach / (HBM_PEAK_GBS * world), 4),
-                         "traffic": None, "kernel": "k_bulk, whole job (all ranks)",
+                         "traffic": None, "kernel": "k_bulk_split (16-step passes), whole job (all ranks)" if cycle == 16 else "k_bulk_split / k_pass_pml (8-step passes), whole job (all ranks)",
                          "bytes_per_cell_step": bpc},
             "weak_scaling": {"single_gpu_same_slab": round(single_v, 1),
                              "efficiency": round(value / (world * single_v), 4)},

@@ -18,7 +18,7 @@ BOUNDARY_NONE, BOUNDARY_MUR5, BOUNDARY_PML = 0, 1, 2
 SRC_NONE, SRC_RICKER, SRC_SINUSOIDAL = 0, 1, 2
 FIELD_EZ, FIELD_HX, FIELD_HY = 0, 1, 2
 
-OPT_MAX_PASS_STEPS, OPT_BAND_ROWS, OPT_ZONE_SPLIT, OPT_LEVEL_SPLIT, OPT_SPLIT_WAVES, OPT_AUTOTUNE = 0, 1, 2, 3, 4, 5
+OPT_MAX_PASS_STEPS, OPT_BAND_ROWS, OPT_ZONE_SPLIT, OPT_LEVEL_SPLIT, OPT_SPLIT_WAVES, OPT_AUTOTUNE, OPT_LONG_SHAPE = 0, 1, 2, 3, 4, 5, 6
 
 E_ARG, E_NODEVICE, E_NOMEM, E_STATE, E_COURANT = -1, -2, -3, -4, -5
 

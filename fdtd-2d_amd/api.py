@@ -152,9 +152,23 @@ def courant_number(eps, mu, dt, dx):
 _cache: dict = {}
 
 
+def invalidate_cache():
+    """Drop the engines the per-call drop-ins keep between calls (frees their device memory)."""
+    while _cache:
+        _cache.popitem()[1][0].close()
+
+
+def _content_sig(a):
+    """Content hash of a material array: any in-place edit changes it (a sum would not notice a
+    moved structure)."""
+    import zlib
+    a = np.ascontiguousarray(a)
+    return a.shape, a.dtype.str, zlib.adler32(a.view(np.uint8).reshape(-1))
+
+
 def _engine_for(Ez, mu, eps, dt, dx) -> Engine:
-    """One cached engine per (shape, dtype, dt, dx); materials are re-sent when the
-    arrays' content may have changed (cheap identity + checksum test)."""
+    """One cached engine per (shape, dtype, dt, dx); materials are re-sent whenever the
+    arrays' content differs from what the engine holds (content hash, not identity)."""
     Ez = np.asarray(Ez)
     if Ez.dtype not in (np.float32, np.float64):
         raise TypeError("fields must be float32 or float64 arrays")
@@ -167,8 +181,7 @@ def _engine_for(Ez, mu, eps, dt, dx) -> Engine:
         _cache[key] = ent
     eng = ent[0]
     eps_a, mu_a = np.asarray(eps), np.asarray(mu)
-    sig = (eps_a.__array_interface__["data"][0], mu_a.__array_interface__["data"][0],
-           float(eps_a.sum()), float(mu_a.sum()), float(eps_a.flat[0]), float(mu_a.flat[0]))
+    sig = (_content_sig(eps_a), _content_sig(mu_a))
     if ent[1] != sig:
         eng.set_materials(eps_a.astype(Ez.dtype, copy=False), mu_a.astype(Ez.dtype, copy=False))
         ent[1] = sig
@@ -245,7 +258,7 @@ def step(E, Hx, Hy, eps, mu, source, t, *, dt=5e-14, dx=1e-4):
 
 
 def run_fdtd(rows=200, cols=200, dt=5e-14, dx=1e-4, nsteps=1000, eps=None, mu=None,
-             source=("ricker", None, None, 30e9), boundary="mur", dtype=np.float32,
+             source=("ricker", None, None, 30e9), boundary="mur", dtype=np.float64,
              devices=1, on_frame=None, nframes=200, device=0):
     """python-src/fdtd.py:13-40 without the video: zero fields, Courant check, nsteps of
     H -> E -> source with t = i*dt, fields resident on the GPU throughout.
@@ -254,7 +267,8 @@ def run_fdtd(rows=200, cols=200, dt=5e-14, dx=1e-4, nsteps=1000, eps=None, mu=No
     with row/col None = grid centre (fdtd.py:34), or None; an optional fifth element
     (nrows, ncols) makes it a line / patch source starting at (row, col).  on_frame(i, Ez) is called
     every nsteps//nframes steps with a host copy of Ez (the snapshot cadence of
-    fdtd.py:36-38).  Returns (Ez, Hx, Hy) as host arrays of `dtype`.
+    fdtd.py:36-38).  Returns (Ez, Hx, Hy) as host arrays of `dtype`.  dtype defaults to float64, what
+    the reference computes in (main.py:81-85); BASELINE's GPU configurations pass float32.
     """
     if devices != 1:
         from .slab import run_fdtd_distributed

@@ -46,7 +46,7 @@ struct fdtd2d {
     void *pml = nullptr;                  // PML only: 4 row + 4 column factor arrays, back to back
     bool have_pml = false;
     int pml_L = 0;
-    int pml_short_rows = 16;     // band height of the layer waves (FDTD2D_PML_SHORT overrides)
+    int pml_short_rows = 16;     // band height of the layer waves
     int nfields() const { return boundary == FDTD2D_BOUNDARY_PML ? 4 : 3; }
     bool have_mat = false, ce_uniform = true, ch_uniform = true;
     double ce_u = 0, ch_u = 0;   // uniform coefficients, already rounded to T
@@ -74,6 +74,10 @@ struct fdtd2d {
     void *scratch = nullptr;     // device scratch for snapshots / reduction partials
     size_t scratch_bytes = 0;
     std::string err;
+#ifdef FDTD2D_TRACE
+    void *trace_dev = nullptr;   // 4 x u64 per workgroup of the last level-split launch (profiling build)
+    long long trace_blocks = 0;
+#endif
 
     bool top() const { return row0 == 0; }
     bool bottom() const { return row0 + nrows == rows; }
@@ -84,7 +88,7 @@ struct fdtd2d {
     void *ezx() const { return ezxb[hcur]; }
     void *hx() const { return hxb[hcur]; }
     void *hy() const { return hyb[hcur]; }
-    int stream_band_rows = 0;    // 0 = heuristic (FDTD2D_BAND_ROWS overrides)
+    int stream_band_rows = 0;    // 0 = heuristic (FDTD2D_OPT_BAND_ROWS)
     int level_split = -1;        // k_bulk_split for 8-step passes: -1 / 1 = yes (measured faster than
                                  // k_bulk at every size, float32 and float64:
                                  // profiles/r01_split8_vs_bulk.txt), 0 = k_bulk
@@ -104,8 +108,9 @@ struct fdtd2d {
         int band_rows, waves;
     };
     std::map<std::array<int, 3>, Shape> tuned;
-    int autotune = 1;            // FDTD2D_OPT_AUTOTUNE / FDTD2D_AUTOTUNE=0
-    int xcd_map = 0;             // FDTD2D_XCD_MAP: XCD-aware order of the strips in k_bulk_split
+    int autotune = 1;            // FDTD2D_OPT_AUTOTUNE
+    Shape long_shape{0, 0};      // FDTD2D_OPT_LONG_SHAPE: shape of full-length passes given by the caller
+                                 // (a shape measured elsewhere, e.g. by another process)
     Shape shape_now{0, 0};       // shape of the launch being issued (set by launch_pass)
     Shape shape_last{0, 0};      // band height / waves per strip actually used by the last pass
     int split_waves = 0;         // waves per strip in k_bulk_split: 0 = automatic, 4 or 8
@@ -132,9 +137,8 @@ struct fdtd2d {
             return 16;
         return std::min(max_nt, 8);
     }
-    int zone_split = -1;         // -1: by launch size; 0/1: force fused / side-stream zones (FDTD2D_ZONE_SPLIT)
-    int edge_band_div = 1;       // edge strips use band_rows / this (FDTD2D_EDGE_DIV; measured: no gain)
-    int max_nt = 16;             // longest pass; FDTD2D_MAX_NT / set_option override (0: step kernels only)
+    int zone_split = -1;         // -1: by launch size; 0/1: force fused / side-stream zones (FDTD2D_OPT_ZONE_SPLIT)
+    int max_nt = 16;             // longest pass; FDTD2D_OPT_MAX_PASS_STEPS (0: step kernels only)
 };
 
 

@@ -51,8 +51,47 @@ double get_elem(const void *p, int dt, size_t i)
     return dt == FDTD2D_F64 ? ((const double *)p)[i] : (double)((const float *)p)[i];
 }
 
+// Field storage starts 64 B past a 128-B boundary: a strip of the 16-step pass begins HC = 16
+// columns left of a multiple of OW = 224 columns (896 B = 7 cache lines), so with this offset every
+// strip row is exactly 8 whole 128-B lines instead of 9 partly used ones.
+constexpr size_t FIELD_SHIFT = 64, FIELD_GUARD = 256;
+
+int alloc_field(fdtd2d *h, void **p)
+{
+    char *raw = nullptr;
+    if (hipMalloc((void **)&raw, h->field_bytes + FIELD_GUARD + FIELD_SHIFT) != hipSuccess)
+        return fail(h, FDTD2D_E_NOMEM, "hipMalloc of %zu bytes failed", h->field_bytes);
+    if (hipMemsetAsync(raw, 0, h->field_bytes + FIELD_GUARD + FIELD_SHIFT, h->stream) != hipSuccess) {
+        (void)hipFree(raw);
+        return fail(h, FDTD2D_E_NOMEM, "hipMemset of a new field failed");
+    }
+    *p = raw + FIELD_SHIFT;
+    return 0;
+}
+
+void free_field(void **p)
+{
+    if (*p) (void)hipFree((char *)*p - FIELD_SHIFT);
+    *p = nullptr;
+}
+
+int need_scratch(fdtd2d *h, size_t bytes)
+{
+    if (h->scratch_bytes >= bytes) return 0;
+    if (h->scratch) (void)hipFree(h->scratch);
+    h->scratch = nullptr;
+    h->scratch_bytes = 0;
+    if (hipMalloc(&h->scratch, bytes) != hipSuccess) return fail(h, FDTD2D_E_NOMEM, "scratch allocation failed");
+    h->scratch_bytes = bytes;
+    return 0;
+}
+
+// rows per staging chunk when host and engine types differ (64 MiB of the wider type)
+int convert_chunk_rows(int host_cols) { return std::max(1, (int)((64u << 20) / ((size_t)host_cols * 8))); }
+
 // Copy host rows (host_cols elements each, of host_dtype) into device rows starting at
-// stored row `srow`, converting to the engine's type when they differ.
+// stored row `srow`.  When the types differ the rows are staged on the device in the host's type
+// and converted there (no host-side loop over the elements).
 int copy_in(fdtd2d *h, void *dev, const void *host, int host_dtype, int srow, int nrows,
             int host_cols)
 {
@@ -63,23 +102,25 @@ int copy_in(fdtd2d *h, void *dev, const void *host, int host_dtype, int srow, in
                               (size_t)host_cols * h->esz, nrows, hipMemcpyHostToDevice));
         return 0;
     }
-    const int chunk = std::max(1, (int)((64u << 20) / ((size_t)host_cols * h->esz)));
-    std::vector<char> tmp((size_t)std::min(chunk, nrows) * host_cols * h->esz);
+    const size_t hsz = host_dtype == FDTD2D_F64 ? 8 : 4;
+    const int chunk = std::min(nrows, convert_chunk_rows(host_cols));
+    int rc = need_scratch(h, (size_t)chunk * host_cols * hsz);
+    if (rc) return rc;
     for (int r = 0; r < nrows; r += chunk) {
         const int n = std::min(chunk, nrows - r);
-        const size_t cnt = (size_t)n * host_cols, off = (size_t)r * host_cols;
-        if (h->dtype == FDTD2D_F32) {
-            float *t = (float *)tmp.data();
-            const double *s = (const double *)host + off;
-            for (size_t i = 0; i < cnt; ++i) t[i] = (float)s[i];
-        } else {
-            double *t = (double *)tmp.data();
-            const float *s = (const float *)host + off;
-            for (size_t i = 0; i < cnt; ++i) t[i] = (double)s[i];
-        }
-        HIPCHK(h, hipMemcpy2D(d + (size_t)r * h->pitch * h->esz, h->pitch * h->esz, tmp.data(),
-                              (size_t)host_cols * h->esz, (size_t)host_cols * h->esz, n,
-                              hipMemcpyHostToDevice));
+        const size_t cnt = (size_t)n * host_cols;
+        HIPCHK(h, hipMemcpyAsync(h->scratch, (const char *)host + (size_t)r * host_cols * hsz, cnt * hsz,
+                                 hipMemcpyHostToDevice, h->stream));
+        const unsigned blocks = (unsigned)std::min<size_t>((cnt + 255) / 256, 4096);
+        char *dd = d + (size_t)r * h->pitch * h->esz;
+        if (h->dtype == FDTD2D_F32)
+            hipLaunchKernelGGL((fdtd::k_convert2d<double, float>), dim3(blocks), dim3(256), 0, h->stream,
+                               (const double *)h->scratch, (size_t)host_cols, (float *)dd, (size_t)h->pitch, n, host_cols);
+        else
+            hipLaunchKernelGGL((fdtd::k_convert2d<float, double>), dim3(blocks), dim3(256), 0, h->stream,
+                               (const float *)h->scratch, (size_t)host_cols, (double *)dd, (size_t)h->pitch, n, host_cols);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipStreamSynchronize(h->stream));      // the staging buffer is reused by the next chunk
     }
     return 0;
 }
@@ -94,23 +135,25 @@ int copy_out(fdtd2d *h, const void *dev, void *host, int host_dtype, int srow, i
                               (size_t)host_cols * h->esz, nrows, hipMemcpyDeviceToHost));
         return 0;
     }
-    const int chunk = std::max(1, (int)((64u << 20) / ((size_t)host_cols * h->esz)));
-    std::vector<char> tmp((size_t)std::min(chunk, nrows) * host_cols * h->esz);
+    const size_t hsz = host_dtype == FDTD2D_F64 ? 8 : 4;
+    const int chunk = std::min(nrows, convert_chunk_rows(host_cols));
+    int rc = need_scratch(h, (size_t)chunk * host_cols * hsz);
+    if (rc) return rc;
     for (int r = 0; r < nrows; r += chunk) {
         const int n = std::min(chunk, nrows - r);
-        const size_t cnt = (size_t)n * host_cols, off = (size_t)r * host_cols;
-        HIPCHK(h, hipMemcpy2D(tmp.data(), (size_t)host_cols * h->esz,
-                              d + (size_t)r * h->pitch * h->esz, h->pitch * h->esz,
-                              (size_t)host_cols * h->esz, n, hipMemcpyDeviceToHost));
-        if (h->dtype == FDTD2D_F32) {
-            const float *t = (const float *)tmp.data();
-            double *s = (double *)host + off;
-            for (size_t i = 0; i < cnt; ++i) s[i] = (double)t[i];
-        } else {
-            const double *t = (const double *)tmp.data();
-            float *s = (float *)host + off;
-            for (size_t i = 0; i < cnt; ++i) s[i] = (float)t[i];
-        }
+        const size_t cnt = (size_t)n * host_cols;
+        const unsigned blocks = (unsigned)std::min<size_t>((cnt + 255) / 256, 4096);
+        const char *dd = d + (size_t)r * h->pitch * h->esz;
+        if (h->dtype == FDTD2D_F32)
+            hipLaunchKernelGGL((fdtd::k_convert2d<float, double>), dim3(blocks), dim3(256), 0, h->stream,
+                               (const float *)dd, (size_t)h->pitch, (double *)h->scratch, (size_t)host_cols, n, host_cols);
+        else
+            hipLaunchKernelGGL((fdtd::k_convert2d<double, float>), dim3(blocks), dim3(256), 0, h->stream,
+                               (const double *)dd, (size_t)h->pitch, (float *)h->scratch, (size_t)host_cols, n, host_cols);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipMemcpyAsync((char *)host + (size_t)r * host_cols * hsz, h->scratch, cnt * hsz,
+                                 hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
     }
     return 0;
 }
@@ -118,9 +161,9 @@ int copy_out(fdtd2d *h, const void *dev, void *host, int host_dtype, int srow, i
 int zero_fields(fdtd2d *h)
 {
     for (void *p : {h->ez[0], h->ez[1], h->hxb[0], h->hxb[1], h->hyb[0], h->hyb[1]})
-        HIPCHK(h, hipMemsetAsync(p, 0, h->field_bytes + 256, h->stream));
+        HIPCHK(h, hipMemsetAsync(p, 0, h->field_bytes + FIELD_GUARD, h->stream));
     for (void *p : {h->ezxb[0], h->ezxb[1]})
-        if (p) HIPCHK(h, hipMemsetAsync(p, 0, h->field_bytes + 256, h->stream));
+        if (p) HIPCHK(h, hipMemsetAsync(p, 0, h->field_bytes + FIELD_GUARD, h->stream));
     h->cur = 0;
     h->hcur = 0;
     h->ev = h->hv = Range{h->store_lo(), h->store_hi()};
@@ -233,6 +276,17 @@ int need_ready(fdtd2d *h)
     return use_device(h);
 }
 
+// the loop entry points refuse to run an unstable configuration (the assert of fdtd.py:28)
+int need_stable(fdtd2d *h)
+{
+    int rc = need_ready(h);
+    if (rc) return rc;
+    const double c = fdtd2d_courant(h);
+    if (c > 1.0)
+        return fail(h, FDTD2D_E_COURANT, "Courant stability condition not met: %.17g > 1.0", c);
+    return 0;
+}
+
 int do_update_h(fdtd2d *h)
 {
     // Hx[i] needs Ez[i], Ez[i+1] (main.py:69-70): the H range shrinks to where both are current
@@ -295,7 +349,7 @@ namespace fdtd_host {
 // Can a pass of nt steps run from the current state?  Fills the row range of the bulk.
 bool pass_geometry(const fdtd2d *h, int nt, int *band_lo, int *band_hi)
 {
-    if (h->probe_cap && (nt == 12 || h->boundary == FDTD2D_BOUNDARY_PML))
+    if (h->probe_cap && h->boundary == FDTD2D_BOUNDARY_PML)
         return false;          // no probe tile for these: the run falls back to shorter passes / single steps
     if (h->boundary == FDTD2D_BOUNDARY_PML) {
         // k_pass_pml: 8-step passes, uniform mu, bands over all rows (no zones)
@@ -344,29 +398,29 @@ template <class T> int make_coef(fdtd2d *h, void *arr)
     return 0;
 }
 
-// scan a host array: min value, and whether all elements (after rounding to T) are equal
+// min, max and positivity of the stored rows [srow, srow+nrows) x cols of a device array of type T
 template <class T>
-void scan_host(const void *p, int host_dtype, size_t n, double *mn, bool *uniform, double *first)
+int scan_device(fdtd2d *h, const void *arr, int srow, int nrows, double *mn, double *mx, bool *positive)
 {
-    double m = get_elem(p, host_dtype, 0);
-    const T f = (T)m;
-    bool u = true;
-    if (host_dtype == FDTD2D_F64) {
-        const double *s = (const double *)p;
-        for (size_t i = 0; i < n; ++i) {
-            m = std::min(m, s[i]);
-            u = u && ((T)s[i] == f);
-        }
-    } else {
-        const float *s = (const float *)p;
-        for (size_t i = 0; i < n; ++i) {
-            m = std::min(m, (double)s[i]);
-            u = u && ((T)s[i] == f);
-        }
+    const int blocks = 1024;
+    int rc = need_scratch(h, (size_t)blocks * 3 * sizeof(double));
+    if (rc) return rc;
+    hipLaunchKernelGGL((fdtd::k_minmax<T>), dim3(blocks), dim3(256), 0, h->stream,
+                       (const T *)arr + (size_t)srow * h->pitch, (double *)h->scratch, (size_t)h->pitch, nrows, h->cols);
+    HIPCHK(h, hipGetLastError());
+    std::vector<double> part((size_t)blocks * 3);
+    HIPCHK(h, hipMemcpyAsync(part.data(), h->scratch, part.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    double a = 1e300, b = -1e300, bad = 0;
+    for (int k = 0; k < blocks; ++k) {
+        a = std::min(a, part[3 * k]);
+        b = std::max(b, part[3 * k + 1]);
+        bad += part[3 * k + 2];
     }
-    *mn = m;
-    *uniform = u;
-    *first = (double)f;
+    *mn = a;
+    *mx = b;
+    *positive = bad == 0;
+    return 0;
 }
 
 int create_impl(fdtd2d_t **out, int rows, int cols, int row0, int nrows, int halo, double dt,
@@ -436,26 +490,20 @@ int create_impl(fdtd2d_t **out, int rows, int cols, int row0, int nrows, int hal
         hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking) != hipSuccess)
         return bail(fail(h, FDTD2D_E_NODEVICE, "hipEventCreate / hipStreamCreate failed"));
     for (void **p : {&h->ez[0], &h->ez[1], &h->hxb[0], &h->hxb[1], &h->hyb[0], &h->hyb[1]}) {
-        // +256 B guard: the last lane of a row may look one vector past the row end
-        if (hipMalloc(p, h->field_bytes + 256) != hipSuccess)
-            return bail(fail(h, FDTD2D_E_NOMEM, "hipMalloc of %zu bytes failed", h->field_bytes));
+        // (+256 B guard: the last lane of a row may look one vector past the row end)
+        if ((rc = alloc_field(h, p))) return bail(rc);
     }
     if (hipMalloc(&h->trash, fdtd::TRASH_SLOTS * fdtd::TRASH_SLOT_BYTES) != hipSuccess)
         return bail(fail(h, FDTD2D_E_NOMEM, "hipMalloc of the scratch line failed"));
     if (boundary == FDTD2D_BOUNDARY_PML) {
         const size_t fb = (size_t)(h->rows + h->cols) * 4 * h->esz;
-        if (hipMalloc(&h->ezxb[0], h->field_bytes + 256) != hipSuccess ||
-            hipMalloc(&h->ezxb[1], h->field_bytes + 256) != hipSuccess || hipMalloc(&h->pml, fb) != hipSuccess)
+        if (alloc_field(h, &h->ezxb[0]) || alloc_field(h, &h->ezxb[1]) || hipMalloc(&h->pml, fb) != hipSuccess)
             return bail(fail(h, FDTD2D_E_NOMEM, "hipMalloc of the PML arrays failed"));
     }
-    if (const char *e2 = std::getenv("FDTD2D_BAND_ROWS")) h->stream_band_rows = std::atoi(e2);
-    if (const char *e3 = std::getenv("FDTD2D_AUTOTUNE")) h->autotune = std::atoi(e3) != 0;
-    if (const char *e4 = std::getenv("FDTD2D_XCD_MAP")) h->xcd_map = std::atoi(e4) != 0;
-    if (const char *e2 = std::getenv("FDTD2D_MAX_NT")) { h->max_nt = std::atoi(e2); h->max_nt_forced = true; }
-    if (const char *e2 = std::getenv("FDTD2D_EDGE_DIV")) h->edge_band_div = std::max(1, std::atoi(e2));
-    if (const char *e2 = std::getenv("FDTD2D_ZONE_SPLIT")) h->zone_split = std::atoi(e2);
-    if (const char *e2 = std::getenv("FDTD2D_LEVEL_SPLIT")) h->level_split = std::atoi(e2);
-    if (const char *e2 = std::getenv("FDTD2D_PML_SHORT")) h->pml_short_rows = std::max(1, std::atoi(e2));
+#ifdef FDTD2D_TRACE
+    if (hipMalloc(&h->trace_dev, (size_t)(1 << 16) * 32) != hipSuccess)
+        return bail(fail(h, FDTD2D_E_NOMEM, "hipMalloc of the trace buffer failed"));
+#endif
     rc = zero_fields(h);
     if (rc) return bail(rc);
     if (hipStreamSynchronize(h->stream) != hipSuccess)
@@ -464,17 +512,14 @@ int create_impl(fdtd2d_t **out, int rows, int cols, int row0, int nrows, int hal
     return 0;
 }
 
+// Upload eps / mu for the stored rows, find min / uniformity ON THE DEVICE (the Courant number of
+// fdtd.py:25-26 needs min(eps), min(mu); a constant array is replaced by its scalar coefficient),
+// then turn the arrays that stay into coefficient arrays in place.
 template <class T>
 int set_materials_impl(fdtd2d *h, const void *eps, const void *mu, int host_dtype,
                        const double *corner, int allow_uniform)
 {
     const int slo = h->store_lo(), shi = h->store_hi();
-    const size_t n = (size_t)(shi - slo) * h->cols;
-    double emin, mmin, e0, m0;
-    bool eu, mu_u;
-    scan_host<T>(eps, host_dtype, n, &emin, &eu, &e0);
-    scan_host<T>(mu, host_dtype, n, &mmin, &mu_u, &m0);
-    if (!(emin > 0) || !(mmin > 0)) return fail(h, FDTD2D_E_ARG, "eps and mu must be positive");
     double eps00, mu00;
     if (corner) {
         eps00 = corner[0];
@@ -486,31 +531,34 @@ int set_materials_impl(fdtd2d *h, const void *eps, const void *mu, int host_dtyp
         return fail(h, FDTD2D_E_ARG, "corner {eps[0,0], mu[0,0]} is required for a slab that does "
                                      "not store global row 0");
     }
+    h->have_mat = false;
+    auto setup = [&](void **arr, const void *host, double *mn, bool *uniform, double *cu) -> int {
+        int rc;
+        if (!*arr && (rc = alloc_field(h, arr))) return rc;
+        else HIPCHK(h, hipMemsetAsync(*arr, 0, h->field_bytes + FIELD_GUARD, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        const int srow = slo - h->row_base();
+        if ((rc = copy_in(h, *arr, host, host_dtype, srow, shi - slo, h->cols))) return rc;
+        double mx;
+        bool positive;
+        if ((rc = scan_device<T>(h, *arr, srow, shi - slo, mn, &mx, &positive))) return rc;
+        if (!positive) return fail(h, FDTD2D_E_ARG, "eps and mu must be positive");
+        *uniform = (*mn == mx) && allow_uniform;
+        if (*uniform) {
+            free_field(arr);
+            *cu = coef_of<T>(*mn, h->dt, h->dx);
+            return 0;
+        }
+        return make_coef<T>(h, *arr);
+    };
+    double emin = 0, mmin = 0;
+    int rc = setup(&h->ce, eps, &emin, &h->ce_uniform, &h->ce_u);
+    if (rc) return rc;
+    rc = setup(&h->ch, mu, &mmin, &h->ch_uniform, &h->ch_u);
+    if (rc) return rc;
     h->eps_min = emin;
     h->mu_min = mmin;
     h->k_mur = mur_of<T>(eps00, mu00, h->dt, h->dx);
-    h->ce_uniform = eu && allow_uniform;
-    h->ch_uniform = mu_u && allow_uniform;
-    auto setup = [&](bool uniform, void **arr, const void *host, double first, double *cu) -> int {
-        if (uniform) {
-            if (*arr) { (void)hipFree(*arr); *arr = nullptr; }
-            *cu = coef_of<T>(first, h->dt, h->dx);
-            return 0;
-        }
-        if (!*arr) {
-            if (hipMalloc(arr, h->field_bytes + 256) != hipSuccess)
-                return fail(h, FDTD2D_E_NOMEM, "hipMalloc of a coefficient array failed");
-        }
-        HIPCHK(h, hipMemsetAsync(*arr, 0, h->field_bytes + 256, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        int rc = copy_in(h, *arr, host, host_dtype, slo - h->row_base(), shi - slo, h->cols);
-        if (rc) return rc;
-        return make_coef<T>(h, *arr);
-    };
-    int rc = setup(h->ce_uniform, &h->ce, eps, e0, &h->ce_u);
-    if (rc) return rc;
-    rc = setup(h->ch_uniform, &h->ch, mu, m0, &h->ch_u);
-    if (rc) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->have_mat = true;
     return 0;
@@ -571,8 +619,9 @@ void fdtd2d_destroy(fdtd2d_t *h)
     if (hipSetDevice(h->device) == hipSuccess) {
         if (h->stream && h->stream != h->own_stream) (void)hipStreamSynchronize(h->stream);
         if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
-        for (void *p : {h->ez[0], h->ez[1], h->hxb[0], h->hxb[1], h->hyb[0], h->hyb[1], h->ce, h->ch, h->ezxb[0], h->ezxb[1], h->pml})
-            if (p) (void)hipFree(p);
+        for (void **p : {&h->ez[0], &h->ez[1], &h->hxb[0], &h->hxb[1], &h->hyb[0], &h->hyb[1], &h->ce, &h->ch, &h->ezxb[0], &h->ezxb[1]})
+            free_field(p);
+        if (h->pml) (void)hipFree(h->pml);
         if (h->scratch) (void)hipFree(h->scratch);
         if (h->trash) (void)hipFree(h->trash);
         if (h->probe_dev) (void)hipFree(h->probe_dev);
@@ -646,8 +695,7 @@ int fdtd2d_set_materials_uniform(fdtd2d_t *h, double eps, double mu)
     h->tuned.clear();
     int rc = use_device(h);
     if (rc) return rc;
-    for (void **p : {&h->ce, &h->ch})
-        if (*p) { (void)hipFree(*p); *p = nullptr; }
+    for (void **p : {&h->ce, &h->ch}) free_field(p);
     h->ce_uniform = h->ch_uniform = true;
     h->eps_min = eps;
     h->mu_min = mu;
@@ -827,6 +875,7 @@ static int tune_pass(fdtd2d *h, int nt, int lo, int hi, bool zt, bool zb)
 {
     const std::array<int, 3> key{nt, lo, hi};
     if (!h->autotune || h->stream_band_rows > 0 || nt < 8 || h->boundary != FDTD2D_BOUNDARY_MUR5 ||
+        (h->long_shape.band_rows > 0 && nt == h->cycle_steps()) ||
         (size_t)std::max(0, hi - lo) * h->cols < ((size_t)4 << 20) || h->tuned.count(key))
         return 0;
     std::vector<fdtd2d::Shape> cand{{0, 0}};
@@ -881,7 +930,7 @@ static int tune_pass(fdtd2d *h, int nt, int lo, int hi, bool zt, bool zb)
 
 int fdtd2d_prepare(fdtd2d_t *h, int nsteps)
 {
-    int rc = need_ready(h);
+    int rc = need_stable(h);
     if (rc) return rc;
     if (h->pend_nt) return fail(h, FDTD2D_E_STATE, "a partial pass is pending: commit it first");
     // the pass lengths fdtd2d_run(nsteps) will use from the current state (same decisions as its
@@ -918,7 +967,7 @@ int fdtd2d_prepare(fdtd2d_t *h, int nsteps)
 
 int fdtd2d_run(fdtd2d_t *h, int nsteps, int src_row, int src_col, const double *amps)
 {
-    int rc = need_ready(h);
+    int rc = need_stable(h);
     if (rc) return rc;
     if (h->pend_nt) return fail(h, FDTD2D_E_STATE, "a partial pass is pending: commit it first");
     if (nsteps < 0) return fail(h, FDTD2D_E_ARG, "nsteps < 0");
@@ -952,10 +1001,8 @@ int fdtd2d_run(fdtd2d_t *h, int nsteps, int src_row, int src_col, const double *
         }
         // longest temporally blocked pass that fits, else one plain step
         int nt = 0, lo = 0, hi = 0;
-        for (int c : {16, 12, 8, 4, 2, 1})
-            if (c <= nsteps - n && (c != 12 || h->max_nt == 12) && (c != 16 || h->cycle_steps() == 16) &&
-                (c <= 8 || (h->dtype == FDTD2D_F32 && (c == 16 || (h->ce_uniform && h->ch_uniform)))) &&
-                pass_geometry(h, c, &lo, &hi)) {
+        for (int c : {16, 8, 4, 2, 1})
+            if (c <= nsteps - n && (c != 16 || h->cycle_steps() == 16) && pass_geometry(h, c, &lo, &hi)) {
                 nt = c;
                 break;
             }
@@ -982,7 +1029,7 @@ int fdtd2d_run(fdtd2d_t *h, int nsteps, int src_row, int src_col, const double *
 int fdtd2d_pass_rows(fdtd2d_t *h, int nt, int row_lo, int row_hi, int src_row, int src_col,
                      const double *amps)
 {
-    int rc = need_ready(h);
+    int rc = need_stable(h);
     if (rc) return rc;
     if (h->pend_nt && h->pend_nt != nt)
         return fail(h, FDTD2D_E_STATE, "a %d-step pass is pending; cannot add rows of a %d-step pass",
@@ -1114,6 +1161,12 @@ int fdtd2d_set_option(fdtd2d_t *h, int option, long long value)
         h->zone_split = (int)value;
         h->tuned.clear();
         return 0;
+    case FDTD2D_OPT_LONG_SHAPE: {
+        const int br = (int)(value & 0xffff), nw = (int)(value >> 16);
+        if (value < 0 || (nw != 0 && nw != 4 && nw != 8)) return fail(h, FDTD2D_E_ARG, "shape = band rows + 65536 * waves (0, 4 or 8)");
+        h->long_shape = fdtd2d::Shape{br, nw};
+        return 0;
+    }
     default: return fail(h, FDTD2D_E_ARG, "unknown option %d", option);
     }
 }
@@ -1124,6 +1177,19 @@ int fdtd2d_sync(fdtd2d_t *h)
     int rc = use_device(h);
     if (rc) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
+#ifdef FDTD2D_TRACE      // profiling build: dump the stamps of the last level-split launch
+    if (const char *path = std::getenv("FDTD2D_TRACE_FILE")) {
+        if (h->trace_blocks > 0) {
+            std::vector<unsigned long long> t((size_t)h->trace_blocks * 4);
+            HIPCHK(h, hipMemcpy(t.data(), h->trace_dev, t.size() * 8, hipMemcpyDeviceToHost));
+            if (FILE *f = std::fopen(path, "w")) {
+                for (long long b = 0; b < h->trace_blocks; ++b)
+                    std::fprintf(f, "%lld %llu %llu %llu %llu\n", b, t[4 * b], t[4 * b + 1], t[4 * b + 2], t[4 * b + 3]);
+                std::fclose(f);
+            }
+        }
+    }
+#endif
     return 0;
 }
 
@@ -1175,17 +1241,6 @@ int fdtd2d_halo_unpack(fdtd2d_t *h, int side, const void *dev_buf)
         if (h->ev.hi >= h->row0 + h->nrows) h->ev.hi = first + h->halo;
         if (h->hv.hi >= h->row0 + h->nrows) h->hv.hi = first + h->halo;
     }
-    return 0;
-}
-
-static int need_scratch(fdtd2d *h, size_t bytes)
-{
-    if (h->scratch_bytes >= bytes) return 0;
-    if (h->scratch) (void)hipFree(h->scratch);
-    h->scratch = nullptr;
-    h->scratch_bytes = 0;
-    if (hipMalloc(&h->scratch, bytes) != hipSuccess) return fail(h, FDTD2D_E_NOMEM, "scratch allocation failed");
-    h->scratch_bytes = bytes;
     return 0;
 }
 

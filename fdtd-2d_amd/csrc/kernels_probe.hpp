@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void k_probe(const PassParams<T> p, const Prob
             }
         }
         __syncthreads();
-        MurRules<T, TileAcc<T, CE_ARR>> rules{{Eo, sX, sY, p.ce, p.ce_u, g, g.R, g.C, z0, c0, WP}, p.k};
+        MurRules<T, TileAcc<T, CE_ARR>> rules{{Eo, sX, sY, p.ce, p.ce_u, g, g.R, g.C, z0, c0, WP, nr, nc}, p.k};
         for (int n = threadIdx.x; n < cells; n += 256) {          // E half-step, stages A-D per cell
             const int li = n / nc, lj = n - li * nc, i = z0 + li, j = c0 + lj;
             const int s = li * WP + lj;

@@ -123,10 +123,7 @@ __device__ __forceinline__ void split_body(const PassParams<T> &p, const int str
     constexpr int LV = NT / SPLIT_NW, LAG = LV + 1;
     constexpr int HC = stream_hc(NT);
     constexpr int SW = 64 * V, OW = SW - 2 * HC;
-#ifndef SPLIT_PF
-#define SPLIT_PF 2
-#endif
-    constexpr int PF = ROLE == 0 ? SPLIT_PF : 0;       // only the first wave hides HBM latency
+    constexpr int PF = ROLE == 0 ? STREAM_PF : 0;      // only the first wave hides HBM latency
     constexpr int S = LV + 2 + PF;              // ring of row slots, tick loop unrolled S times
     const Geom g = p.g;
     const int lane = threadIdx.x & 63;
@@ -233,6 +230,9 @@ __global__ __launch_bounds__(64 * SPLIT_NW) void k_bulk_split(const PassParams<T
                                          (int)sizeof(VecN<T, V>);
     __shared__ VecN<T, V> lds[HAND > ZONE ? HAND : ZONE];
     int b = blockIdx.x;
+#ifdef FDTD2D_TRACE
+    TraceScope trace(p.trace);
+#endif
     if constexpr (FUSE) {    // zone tiles are the first workgroups of the launch (all NW waves per tile)
         const int nzone = (p.zone_top + p.zone_bot) * p.zone_tiles;
         if (b < nzone) {
@@ -244,38 +244,15 @@ __global__ __launch_bounds__(64 * SPLIT_NW) void k_bulk_split(const PassParams<T
         b -= nzone;
     }
     int strip, ra, rb;
-    if (b < 2 * p.nbands_e) {
-        const int sidx = b / p.nbands_e, band = b - sidx * p.nbands_e;
-        if (sidx == 1 && p.nstrips == 1) return;
-        strip = sidx == 0 ? 0 : p.nstrips - 1;
-        ra = p.band_lo + band * p.band_rows_e;
-        rb = min(ra + p.band_rows_e, p.band_hi);
-    } else {
-        b -= 2 * p.nbands_e;
-        int sidx, band;
-        if (p.xcd_map) {
-            // Workgroups go to the 8 XCDs round-robin.  Give XCD x the bands x, x+8, ... and make
-            // the strips of one band consecutive on it: neighbouring strips read the same rows at
-            // the same time, so the cache lines they share (the 32 overlap columns straddle two)
-            // are fetched from HBM once per XCD L2 instead of once per strip.
-            const int inner = p.nstrips - 2, x = b & 7, y = b >> 3, bl = y / inner;
-            sidx = y - bl * inner;
-            band = bl * 8 + x;
-            if (band >= p.nbands) return;
-        } else {
-            sidx = b / p.nbands;
-            band = b - sidx * p.nbands;
-        }
-        strip = sidx + 1;
-        ra = p.band_lo + band * p.band_rows;
-        rb = min(ra + p.band_rows, p.band_hi);
-    }
-    if (ra >= rb) return;
+    if (!strip_of_block(p, b, &strip, &ra, &rb)) return;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int x0 = strip_x0<T, NT, V>(p, strip);
     const bool edge = x0 < 5 || x0 + SW > p.g.C - 5;
     const bool src = p.src_row1 > ra - 2 * NT && p.src_row < rb + NT && p.src_col1 > x0 &&
                      p.src_col < x0 + SW;
+#ifdef FDTD2D_TRACE
+    trace.kind = (edge || src) ? 1 : 2;
+#endif
     // zero the hand-off buffers: the first ticks read rows nobody has written yet
     for (int n = threadIdx.x; n < HAND; n += 64 * SPLIT_NW)
 #pragma unroll

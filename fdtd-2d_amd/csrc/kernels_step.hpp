@@ -259,6 +259,56 @@ __global__ __launch_bounds__(256) void k_reduce(const T *__restrict__ f, double 
     }
 }
 
+// ---- host-layout <-> device-layout rows with a change of element type ----------------------------
+// (fdtd2d_upload / download / set_materials when the host arrays are not of the engine's type:
+// the conversion runs on the device, one rounding per element exactly as a NumPy astype)
+template <class S, class D>
+__global__ __launch_bounds__(256) void k_convert2d(const S *__restrict__ src, size_t src_pitch,
+                                                   D *__restrict__ dst, size_t dst_pitch, int rows, int cols)
+{
+    const size_t n = (size_t)rows * cols;
+    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (size_t)gridDim.x * 256) {
+        const size_t i = t / cols, j = t - i * cols;
+        dst[i * dst_pitch + j] = (D)src[i * src_pitch + j];
+    }
+}
+
+// ---- min / max of a material array on the device (fdtd.py:25-26) --------------
+// Per-block partials {min, max, number of elements that are not > 0 (NaN included)}; the host
+// folds the <= 1024 partials.  min == max <=> the array is uniform.
+template <class T>
+__global__ __launch_bounds__(256) void k_minmax(const T *__restrict__ f, double *__restrict__ part,
+                                                size_t pitch, int nrows, int ncols)
+{
+    __shared__ double smin[256], smax[256], sbad[256];
+    double mn = 1e300, mx = -1e300, bad = 0;
+    const size_t n = (size_t)nrows * ncols;
+    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (size_t)gridDim.x * 256) {
+        const size_t i = t / ncols, j = t - i * ncols;
+        const double v = (double)f[i * pitch + j];
+        if (!(v > 0)) bad += 1;
+        mn = v < mn ? v : mn;
+        mx = v > mx ? v : mx;
+    }
+    smin[threadIdx.x] = mn;
+    smax[threadIdx.x] = mx;
+    sbad[threadIdx.x] = bad;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            smin[threadIdx.x] = smin[threadIdx.x] < smin[threadIdx.x + w] ? smin[threadIdx.x] : smin[threadIdx.x + w];
+            smax[threadIdx.x] = smax[threadIdx.x] > smax[threadIdx.x + w] ? smax[threadIdx.x] : smax[threadIdx.x + w];
+            sbad[threadIdx.x] += sbad[threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        part[3 * blockIdx.x] = smin[0];
+        part[3 * blockIdx.x + 1] = smax[0];
+        part[3 * blockIdx.x + 2] = sbad[0];
+    }
+}
+
 // ---- halo rows <-> contiguous message (3 fields x nrows x C) ---------------------------------
 template <class T, bool PACK>
 __global__ __launch_bounds__(256) void k_halo(T *__restrict__ f0, T *__restrict__ f1,

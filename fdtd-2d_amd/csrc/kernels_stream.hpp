@@ -38,10 +38,10 @@ constexpr int PASS_THREADS = 256;    // threads per zone tile (4 waves share the
 // branched around.  One 4 KiB slot per workgroup (index mod 1024): a single shared line would
 // be written by every CU at once.
 constexpr int TRASH_SLOTS = 1024, TRASH_SLOT_BYTES = 4096;
-constexpr int STREAM_MAX_NT = 16;   // longest pass: 8 (12) levels in one wave, 16 with the level-split kernel
+constexpr int STREAM_MAX_NT = 16;   // longest pass: 8 levels in one wave, 16 with the level-split kernel
 // halo columns per strip side: >= NT (validity shrinks one column per level from a strip
 // edge) and a multiple of 4 so that every lane's 16-byte access stays aligned
-constexpr int stream_hc(int nt) { return nt <= 4 ? 4 : (nt <= 8 ? 8 : (nt <= 12 ? 12 : 16)); }
+constexpr int stream_hc(int nt) { return nt <= 4 ? 4 : (nt <= 8 ? 8 : 16); }
 
 template <class T> struct PassParams {
     const T *ez_in, *hx_in, *hy_in;
@@ -51,8 +51,6 @@ template <class T> struct PassParams {
     Geom g;
     int band_lo, band_hi;      // rows the streaming kernel produces
     int band_rows, nstrips, nbands;
-    int band_rows_e, nbands_e;   // shorter bands for the first/last strip (their GENERAL body is
-                               // slower per row; equal-height bands would make them the tail)
     int zone_top, zone_bot;    // 1 if this launch owns the grid's top / bottom zone
     int zone_tiles;            // column tiles per zone
     int fused_zones;           // 1: the zone tiles are the first workgroups of the k_bulk launch
@@ -60,24 +58,43 @@ template <class T> struct PassParams {
     T *trash;                  // >= 3 x 1 KiB of device scratch: where masked-off stores land
     int src_row, src_col;      // first source cell; the source is the rectangle
     int src_row1, src_col1;    // [src_row, src_row1) x [src_col, src_col1) (all four very negative: none)
-    int xcd_map;               // k_bulk_split: strips of one band are consecutive workgroups of one XCD
     int nlev;                  // time levels this launch really advances (<= NT; the level-split
                                // kernel, the zone tiles and the probe tile skip the rest)
     double amp[STREAM_MAX_NT]; // amplitude added after step s = 1..NT of this pass
+#ifdef FDTD2D_TRACE              // profiling build only (tools/Makefile.trace): per-workgroup time stamps
+    unsigned long long *trace;
+#endif
 };
+
+#ifdef FDTD2D_TRACE
+// {start, end} in shader cycles (s_memtime), kind (0 zone tile, 1 edge strip, 2 plain strip) and
+// the hardware id (XCC << 16 | HW_ID: SE, CU, SIMD of wave 0) of every workgroup of a launch.
+struct TraceScope {
+    unsigned long long *q;
+    unsigned long long t0;
+    int kind = 0;
+    __device__ __forceinline__ TraceScope(unsigned long long *base)
+        : q(base ? base + 4 * (size_t)blockIdx.x : nullptr), t0(__builtin_amdgcn_s_memtime()) {}
+    __device__ __forceinline__ ~TraceScope()
+    {
+        if (q && threadIdx.x == 0) {
+            q[0] = t0;
+            q[1] = __builtin_amdgcn_s_memtime();
+            q[2] = (unsigned long long)kind;
+            q[3] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 16) |
+                   (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffff);
+        }
+    }
+};
+#endif
 
 // ---- lane shifts -----------------------------------------------------------------------
 // from_next(x): lane l gets lane l+1's x; from_prev(x): lane l gets lane l-1's x.
 // (lane 63 / lane 0 get 0: those are strip-edge lanes whose results are never used)
 __device__ __forceinline__ int dpp_next(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x130, 0xF, 0xF, true); }
 __device__ __forceinline__ int dpp_prev(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x138, 0xF, 0xF, true); }
-#ifdef STREAM_EXP_NO_DPP
-__device__ __forceinline__ float from_next(float x) { return x * 0.5f; }
-__device__ __forceinline__ float from_prev(float x) { return x * 0.25f; }
-#else
 __device__ __forceinline__ float from_next(float x) { return __builtin_bit_cast(float, dpp_next(__builtin_bit_cast(int, x))); }
 __device__ __forceinline__ float from_prev(float x) { return __builtin_bit_cast(float, dpp_prev(__builtin_bit_cast(int, x))); }
-#endif
 __device__ __forceinline__ double from_next(double x)
 {
     const long long b = __builtin_bit_cast(long long, x);
@@ -108,14 +125,25 @@ __device__ __forceinline__ int strip_x0(const PassParams<T> &p, int strip)
     return x0;
 }
 
+// Launch order of the (band, strip) tasks: first the edge strips (0 and last: their GENERAL body
+// is the slower one), then strips 1, 2, ...; all bands of one strip are consecutive.
+template <class T>
+__device__ __forceinline__ bool strip_of_block(const PassParams<T> &p, int b, int *strip, int *ra, int *rb)
+{
+    const int sidx = b / p.nbands, band = b - sidx * p.nbands;
+    if (sidx == 1 && p.nstrips == 1) return false;        // the second edge slot stays empty
+    *strip = sidx == 0 ? 0 : (sidx == 1 ? p.nstrips - 1 : sidx - 1);
+    *ra = p.band_lo + band * p.band_rows;
+    *rb = min(*ra + p.band_rows, p.band_hi);
+    return *ra < *rb;
+}
+
 template <class T, bool CE_ARR, bool CH_ARR, int V = Vec<T>::N> struct Slot {
     VecN<T, V> e, x, y;
     VecN<T, V> ce, ch;   // the row's coefficients ride along (only touched when arrays)
 };
 
-#ifndef STREAM_PF
-#define STREAM_PF 2
-#endif
+constexpr int STREAM_PF = 2;   // rows in flight ahead of level 0 (3 or 4 cost a wave per SIMD: profiles/r01_short_pass_cost.txt)
 
 // ---- the streaming kernel ------------------------------------------------------------------
 // GENERAL = false: every column of the strip is a plain interior column and the point
@@ -176,11 +204,6 @@ __device__ __forceinline__ void stream_body(const PassParams<T> &p, const int st
     // vmcnt(0) in front of every level -- which serialises the prefetch (measured: 58 % of
     // wave time in s_waitcnt, profiles/r01_kpass_ablation.txt).
     auto load_row = [&](SlotT &r, int i) {
-#ifdef STREAM_EXP_NO_LOAD
-#pragma unroll
-        for (int v = 0; v < V; ++v) { r.e.v[v] = T(i + v); r.x.v[v] = T(0.5f * i); r.y.v[v] = T(v); }
-        return;
-#endif
         const int ic = min(i, tau1 - 1);             // rows past the band are never used
         const size_t o = at(g, ic, 0) + col;         // lanes outside the grid read column 0
         r.e = ldn<V>(p.ez_in + o);
@@ -218,15 +241,10 @@ __device__ __forceinline__ void stream_body(const PassParams<T> &p, const int st
             load_row(slot[(k + PF) % S], tau + PF);
 #pragma unroll
             for (int t = 1; t <= NT; ++t) {
-#ifdef STREAM_EXP_NO_COMPUTE
-                break;
-#endif
                 const int i = tau - t;                                   // row level t updates now
                 // level t is only needed on rows [ra-(NT-t)-1, rb+(NT-t)): skip the rest of the
                 // pipeline fill and drain (wave-uniform)
-#ifndef STREAM_EXP_NO_SKIP
                 if (i < ra - (NT - t) - 1 || i >= rb + (NT - t)) continue;
-#endif
                 SlotT &c = slot[(k - t + 2 * S) % S];      // row i, level t-1 -> t
                 const SlotT &nx = slot[(k - t + 1 + 2 * S) % S];  // row i+1, level t-1
                 const SlotT &pv = slot[(k - t - 1 + 2 * S) % S];  // row i-1, level t
@@ -315,11 +333,21 @@ template <class T, bool CE_ARR> struct TileAcc {
     T ce_u;
     Geom g;
     int R, C, z0, c0, wlp;
-    __device__ __forceinline__ int idx(int i, int j) const { return (i - z0) * wlp + (j - c0); }
+    int nr, nc;           // rows / columns the tile holds
+    // Cells next to a non-physical tile edge ask the rules for neighbours the tile does not hold
+    // (their results are outside the validity cone and never used).  The index is clamped into the
+    // tile so that such a read stays inside the arrays whatever address space they live in.
+    __device__ __forceinline__ int idx(int i, int j) const
+    {
+        return min(max(i - z0, 0), nr - 1) * wlp + min(max(j - c0, 0), nc - 1);
+    }
     __device__ __forceinline__ T p(int i, int j) const { return P[idx(i, j)]; }
     __device__ __forceinline__ T hx(int i, int j) const { return x[idx(i, j)]; }
     __device__ __forceinline__ T hy(int i, int j) const { return y[idx(i, j)]; }
-    __device__ __forceinline__ T ce(int i, int j) const { return CE_ARR ? cearr[at(g, i, j)] : ce_u; }
+    __device__ __forceinline__ T ce(int i, int j) const
+    {
+        return CE_ARR ? cearr[at(g, min(max(i, 0), R - 1), min(max(j, 0), C - 1))] : ce_u;
+    }
 };
 
 // smem: ZoneDims<NT>::LDS_ELEMS elements of LDS owned by the calling kernel (k_bulk_split shares
@@ -330,9 +358,8 @@ __device__ __forceinline__ void zone_body(const PassParams<T> &p, const int tile
 {
     using D = ZoneDims<NT>;
     static_assert((D::WL & (D::WL - 1)) == 0 && THREADS % D::WL == 0 && D::WZ >= 8, "tile shape");
-    // (offsets from the one LDS base, never a table of pointers: those become generic pointers,
-    // flat loads, and an out-of-tile read of a masked-off lane -- harmless as a ds_read --
-    // leaves the LDS aperture and faults)
+    // (offsets from the one LDS base, never a table of pointers: those become generic pointers and
+    // flat loads; every tile index is clamped into the tile, see TileAcc::idx)
     constexpr int ZS = D::ZR * D::WLP;
     T *const sX = smem + 2 * ZS;
     T *const sY = smem + 3 * ZS;
@@ -392,7 +419,7 @@ __device__ __forceinline__ void zone_body(const PassParams<T> &p, const int tile
         __syncthreads();
         // E half-step: stages A-D as one pure function of (Eo, new H) per cell; plain interior
         // cells (the vast majority) take the direct formula
-        MurRules<T, TileAcc<T, CE_ARR>> rules{{Eo, sX, sY, p.ce, p.ce_u, g, g.R, g.C, z0, c0, D::WLP}, p.k};
+        MurRules<T, TileAcc<T, CE_ARR>> rules{{Eo, sX, sY, p.ce, p.ce_u, g, g.R, g.C, z0, c0, D::WLP, D::ZR, wl}, p.k};
         for (int li = r_lo + lr; li < r_hi; li += RG) {
             const int i = z0 + li;
             const int s = li * D::WLP + lj;
@@ -443,11 +470,8 @@ __device__ __forceinline__ void zone_body(const PassParams<T> &p, const int tile
 // (profiles/r01_kpass_ablation.txt).
 // Minimum waves per SIMD the register allocator must leave room for: 3 (<= 168 VGPRs) for
 // uniform materials -- the slot ring alone is 144 -- and 2 when coefficient rows ride along.
-#ifndef STREAM_WPE
-#define STREAM_WPE(arr) 2
-#endif
 template <class T, int NT, bool CE_ARR, bool CH_ARR, int V = Vec<T>::N>
-__global__ __launch_bounds__(64, STREAM_WPE(CE_ARR || CH_ARR || NT > 8 || sizeof(T) > 4))
+__global__ __launch_bounds__(64, 2)
 void k_bulk(const PassParams<T> p)
 {
     constexpr int SW = 64 * V;
@@ -462,33 +486,14 @@ void k_bulk(const PassParams<T> p)
         }
         b -= nzone;
     }
-    // first the edge strips (0 and last) in their (optionally shorter) bands, then strips
-    // 1, 2, ... in normal bands; all bands of one strip are consecutive
     int strip, ra, rb;
-    if (b < 2 * p.nbands_e) {
-        const int sidx = b / p.nbands_e, band = b - sidx * p.nbands_e;
-        if (sidx == 1 && p.nstrips == 1) return;
-        strip = sidx == 0 ? 0 : p.nstrips - 1;
-        ra = p.band_lo + band * p.band_rows_e;
-        rb = min(ra + p.band_rows_e, p.band_hi);
-    } else {
-        b -= 2 * p.nbands_e;
-        const int sidx = b / p.nbands, band = b - sidx * p.nbands;
-        strip = sidx + 1;
-        ra = p.band_lo + band * p.band_rows;
-        rb = min(ra + p.band_rows, p.band_hi);
-    }
-    if (ra >= rb) return;
+    if (!strip_of_block(p, b, &strip, &ra, &rb)) return;
     const int x0 = strip_x0<T, NT, V>(p, strip);
     // wave-uniform choice: all SW columns plain interior (5 <= j <= C-6) and the source cell
     // outside the rows/columns this wave ever touches -> mask-free body
     const bool edge = x0 < 5 || x0 + SW > p.g.C - 5;
     const bool src = p.src_row1 > ra - 2 * NT && p.src_row < rb + NT && p.src_col1 > x0 &&
                      p.src_col < x0 + SW;
-#ifdef STREAM_EXP_NO_GENERAL
-    stream_body<T, NT, CE_ARR, CH_ARR, false, V>(p, strip, ra, rb);   // timing experiment only
-    return;
-#endif
     if (edge || src)
         stream_body<T, NT, CE_ARR, CH_ARR, true, V>(p, strip, ra, rb);
     else

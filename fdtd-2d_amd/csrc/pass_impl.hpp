@@ -11,14 +11,10 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
     using D = fdtd::ZoneDims<NT>;
     const int region = std::max(0, p.band_hi - p.band_lo);
     p.nbands = (region + p.band_rows - 1) / p.band_rows;
-    p.band_rows_e = std::max(1, h->edge_band_div > 0 ? p.band_rows / h->edge_band_div : p.band_rows);
-    p.nbands_e = (region + p.band_rows_e - 1) / p.band_rows_e;
     p.zone_tiles = (h->cols + D::WZ - 1) / D::WZ;
     // launch order: zone tiles, 2 edge-strip slots (the second stays empty with one strip),
     // then strips 1 .. nstrips-2
-    p.xcd_map = h->xcd_map && (NT == 16 || NT == 8) && h->use_level_split(NT, p.band_lo, p.band_hi) && p.nstrips > 2;
-    const long long bulk = 2LL * p.nbands_e + (long long)(p.xcd_map ? (p.nbands + 7) / 8 * 8 : p.nbands) *
-                                                  std::max(0, p.nstrips - 2);
+    const long long bulk = (long long)p.nbands * (2 + std::max(0, p.nstrips - 2));
     const long long zones = (long long)(p.zone_top + p.zone_bot) * p.zone_tiles;
     if (bulk + zones == 0) return 0;
     if constexpr (NT == 16 || NT == 8) {
@@ -38,6 +34,9 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
                 HIPCHK(h, hipEventRecord(h->ev_join, h->side_stream));
             }
             const long long blocks = bulk + (p.fused_zones ? zones : 0);
+#ifdef FDTD2D_TRACE
+            h->trace_blocks = std::min<long long>(blocks, 1 << 16);
+#endif
             if (blocks > 0) {
                 // (array materials: one more row per slot and hand-off for each coefficient array)
                 const bool w8 = h->split_waves_for(NT, p.band_lo, p.band_hi) == 8;
@@ -60,8 +59,8 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
             return 0;
         }
     }
-    if constexpr (NT > 12) {
-        return fail(h, FDTD2D_E_ARG, "16- and 12-step passes run on the level-split kernel only");
+    if constexpr (NT > 8) {
+        return fail(h, FDTD2D_E_ARG, "16-step passes run on the level-split kernel only");
     } else {
     // Small launches: zone tiles as k_zone on the side stream (ordered behind what is already
     // on h->stream; everything later on h->stream waits for both).  Large launches: fused.
@@ -90,13 +89,9 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
 template <class T, int NT> int launch_pass_nt(fdtd2d *h, fdtd::PassParams<T> &p)
 {
     if (h->ce_uniform && h->ch_uniform) return launch_pass_impl<T, NT, false, false>(h, p);
-    if constexpr (NT == 12)   // k_bulk: the coefficient rows do not fit the register budget beyond 8 levels
-        return fail(h, FDTD2D_E_ARG, "12-step passes need uniform materials");
-    else {
     if (!h->ce_uniform && h->ch_uniform) return launch_pass_impl<T, NT, true, false>(h, p);
     if (h->ce_uniform && !h->ch_uniform) return launch_pass_impl<T, NT, false, true>(h, p);
     return launch_pass_impl<T, NT, true, true>(h, p);
-    }
 }
 
 template <class T, int NT> int launch_probe_nt(fdtd2d *h, const fdtd::PassParams<T> &p, const fdtd::ProbeParams &q)
@@ -131,9 +126,8 @@ template <class T> int launch_probe(fdtd2d *h, int nt, const fdtd::PassParams<T>
     }
 }
 
-#ifdef FDTD_PASS_LONG_EXTERN   // the 12- and 16-step float32 kernels are built in pass_f32_long.hip
+#ifdef FDTD_PASS_LONG_EXTERN   // the 16-step float32 kernels are built in pass_f32_long.hip
 extern template int launch_pass_nt<float, 16>(fdtd2d *, fdtd::PassParams<float> &);
-extern template int launch_pass_nt<float, 12>(fdtd2d *, fdtd::PassParams<float> &);
 #endif
 
 // One pass of nt in {1,2,4,8,16} steps; amps = nt amplitudes or nullptr.
@@ -163,6 +157,10 @@ template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, 
     p.nstrips = (h->cols + OW - 1) / OW;
     int br = h->stream_band_rows;
     h->shape_now = fdtd2d::Shape{0, 0};
+    if (br <= 0 && h->long_shape.band_rows > 0 && nt == h->cycle_steps()) {
+        h->shape_now = h->long_shape;
+        br = h->long_shape.band_rows;
+    }
     if (br <= 0) {
         auto it = h->tuned.find({nt, band_lo, band_hi});
         if (it != h->tuned.end()) {
@@ -208,6 +206,10 @@ template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, 
     if (p.nlev != nt && !h->use_level_split(nt, band_lo, band_hi))
         return fail(h, FDTD2D_E_ARG, "short passes run on the level-split kernel only");
     for (int s = 0; s < fdtd::STREAM_MAX_NT; ++s) p.amp[s] = (amps && s < p.nlev) ? amps[s] : 0.0;
+#ifdef FDTD2D_TRACE
+    p.trace = (unsigned long long *)h->trace_dev;
+    h->trace_blocks = 0;
+#endif
     int rc;
     if (h->probe_pending) {     // the probe cell's own cone, recomputed by one extra workgroup
         h->probe_pending = false;
@@ -246,9 +248,6 @@ template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, 
     case 16:
         if constexpr (sizeof(T) == 4) { rc = launch_pass_nt<T, 16>(h, p); break; }
         return fail(h, FDTD2D_E_ARG, "16-step passes are built for float32 only");
-    case 12:
-        if constexpr (sizeof(T) == 4) { rc = launch_pass_nt<T, 12>(h, p); break; }
-        return fail(h, FDTD2D_E_ARG, "12-step passes are built for float32 only");
     case 8: rc = launch_pass_nt<T, 8>(h, p); break;
     case 4: rc = launch_pass_nt<T, 4>(h, p); break;
     case 2: rc = launch_pass_nt<T, 2>(h, p); break;

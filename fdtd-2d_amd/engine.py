@@ -284,7 +284,7 @@ class Engine:
         return self
 
     def set_option(self, max_pass_steps=None, band_rows=None, zone_split=None, level_split=None,
-                   split_waves=None, autotune=None):
+                   split_waves=None, autotune=None, long_shape=None):
         """Speed knobs of run(): longest temporally blocked pass (0 = single-step kernels
         only) and rows per streaming band.  Results do not depend on them."""
         if max_pass_steps is not None:
@@ -299,6 +299,9 @@ class Engine:
             self._ck(self._lib.fdtd2d_set_option(self._h, _abi.OPT_AUTOTUNE, int(bool(autotune))))
         if split_waves is not None:
             self._ck(self._lib.fdtd2d_set_option(self._h, _abi.OPT_SPLIT_WAVES, int(split_waves)))
+        if long_shape is not None:       # (band rows, waves per strip) of the full-length passes
+            br, nw = long_shape
+            self._ck(self._lib.fdtd2d_set_option(self._h, _abi.OPT_LONG_SHAPE, int(br) + 65536 * int(nw)))
         return self
 
     def sync(self):

@@ -100,9 +100,15 @@ class SlabRunner:
             self.edge_stream = torch.cuda.Stream(device=self.buf_device)
             self.engine.set_stream(self.stream.cuda_stream)
         # overlap: compute the rows next to the cuts first (second stream), send them while
-        # the interior of the slab is still being computed
+        # the interior of the slab is still being computed.  Whether a cycle runs overlapped and
+        # how many steps it has are decided from quantities EVERY rank shares (the slab plan, the
+        # agreed cycle): ranks that disagreed would post their sends and receives in different
+        # orders and deadlock.
         self.boundary = boundary
-        self.overlap = bool(overlap) and self.world > 1 and boundary in ("mur", "mur5")
+        self.min_slab = min(b - a for a, b in self.plan)
+        self.overlap = bool(overlap) and self.world > 1 and self.min_slab >= 2 * self.halo + 1 and \
+            hasattr(self.engine, "pass_rows")
+        self.cycle = None            # steps per exchange, agreed in set_materials()
         self._halo_fresh = False
         if self.world > 1:
             n = self.engine.halo_bytes // self.dtype.itemsize    # 3 fields (4 with the PML's Ezx)
@@ -143,7 +149,32 @@ class SlabRunner:
                                       allow_uniform=allow_uniform)
         if self.boundary == "pml":
             self.engine.set_pml(courant00=(1 / np.sqrt(float(c[0]) * float(c[1])) * self.dt) / self.dx)
+        self._agree_cycle()
         return self
+
+    def set_option(self, **kw):
+        """Engine.set_option on this rank's engine; the steps per exchange are agreed again."""
+        self.engine.set_option(**kw)
+        if self.cycle is not None:
+            self._agree_cycle()
+        return self
+
+    def _agree_cycle(self):
+        """Steps per exchange = the longest pass EVERY rank's engine runs (an engine decides 16 vs
+        8 from its own slab size, and slabs differ by a row): min over the ranks, handed back to
+        the engine so that no rank picks a longer pass."""
+        torch, dist = self.torch, self.dist
+        local = int(getattr(self.engine, "cycle_steps", self.halo) or 0)
+        if self.world > 1:
+            t = torch.tensor([float(local)], dtype=torch.float64)
+            t = self._host_collective(t, lambda x: dist.all_reduce(x, op=dist.ReduceOp.MIN, group=self.group))
+            agreed = int(t[0])
+        else:
+            agreed = local
+        if agreed != local and hasattr(self.engine, "set_option"):
+            self.engine.set_option(max_pass_steps=agreed)
+        self.cycle = min(self.halo, agreed or self.halo) if self.world > 1 else 0
+        return self.cycle
 
     def _global(self, group_rank):
         if self.group is None:
@@ -255,13 +286,13 @@ class SlabRunner:
             if amps.shape[0] < nsteps:
                 raise ValueError("amps shorter than nsteps")
         done = 0
-        can_overlap = self.overlap and (self.r1 - self.r0) >= 2 * self.halo + 1 and \
-            hasattr(self.engine, "pass_rows")
-        # steps per exchange: the longest pass the engine runs in this configuration (16 or 8)
-        cycle = min(self.halo, getattr(self.engine, "cycle_steps", self.halo) or self.halo)
+        if self.world > 1 and self.cycle is None:
+            raise RuntimeError("SlabRunner.set_materials() must be called (by every rank) before run()")
+        # steps per exchange: the longest pass every rank's engine runs (16 or 8), see _agree_cycle
+        cycle = self.cycle
         # grids below 2*(2*cycle+6) rows have no temporally blocked pass (the engine advances
         # them with its single-step kernels), hence nothing to issue in pieces
-        can_overlap = can_overlap and self.rows >= 2 * (2 * cycle + 6)
+        can_overlap = self.overlap and self.rows >= 2 * (2 * cycle + 6)
         with self._on_stream():
             while done < nsteps:
                 n = nsteps - done if self.world == 1 else min(cycle, nsteps - done)
@@ -288,7 +319,7 @@ class SlabRunner:
         prep = getattr(self.engine, "prepare", None)
         if prep is None:
             return self
-        cycle = min(self.halo, getattr(self.engine, "cycle_steps", self.halo) or self.halo) if self.world > 1 else 0
+        cycle = self.cycle or 0
         tail = nsteps % cycle if cycle else nsteps
         with self._on_stream():
             if self.world > 1 and not self._halo_fresh:
@@ -358,7 +389,22 @@ def run_fdtd_distributed(rows, cols, dt, dx, nsteps, eps, mu, source, boundary, 
         sc = cols // 2 if sc is None else sc
         f = {"ricker": ricker_amplitude, "sinusoidal": sinusoidal_amplitude}[kind]
         amps = np.array([f(i * dt, fc) for i in range(nsteps)], dtype=np.float64)
-    runner.run(nsteps, sr, sc, amps)
+    # the snapshot cadence of fdtd.py:36-38: after every step i with i % (nsteps // nframes) == 0
+    # the full Ez is gathered on rank 0 and handed to on_frame there (collective: every rank stops)
+    every = max(1, nsteps // nframes) if on_frame is not None else nsteps
+    done = 0
+    while done < nsteps:
+        if on_frame is None:
+            n = nsteps - done
+        else:
+            nxt = ((done + every - 1) // every) * every
+            n = min(nsteps - done, nxt - done + 1)
+        runner.run(n, sr, sc, None if amps is None else amps[done:done + n])
+        done += n
+        if on_frame is not None and (done - 1) % every == 0:
+            full = runner.gather(0)
+            if full is not None:
+                on_frame(done - 1, full[0])
     out = runner.gather(0)
     runner.close()
     return out

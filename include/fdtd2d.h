@@ -57,7 +57,8 @@ typedef struct fdtd2d fdtd2d_t;
 #define FDTD2D_E_NODEVICE (-2)  /* no gfx950 device / HIP runtime unusable */
 #define FDTD2D_E_NOMEM    (-3)
 #define FDTD2D_E_STATE    (-4)  /* call not valid in the current state (e.g. stale halo) */
-#define FDTD2D_E_COURANT  (-5)  /* Courant number > 1 (fdtd.py:28) */
+#define FDTD2D_E_COURANT  (-5)  /* Courant number > 1 (fdtd.py:28): returned by fdtd2d_run*, fdtd2d_prepare
+                                   and fdtd2d_pass_rows; nothing is launched */
 /* HIP errors: -(1000 + hipError_t) */
 
 /* info selectors for fdtd2d_info() */
@@ -234,6 +235,9 @@ int fdtd2d_sync(fdtd2d_t *h);
                                          times a ladder of band heights (and 4 / 8 waves per strip)
                                          with uncommitted trial launches and keeps the fastest;
                                          0: fixed rules.  Results are identical either way. */
+#define FDTD2D_OPT_LONG_SHAPE      6   /* launch shape of the full-length passes (16 or 8 steps), value =
+                                         band rows + 65536 * waves per strip (0 = automatic): re-use a
+                                         shape the tuner found in another process; 0 clears it */
 int fdtd2d_set_option(fdtd2d_t *h, int option, long long value);
 
 /* ---- row-slab halo exchange (transport is the caller's: RCCL via torch.distributed) -- */

@@ -22,7 +22,8 @@ def worker(rank, world, port, job, outdir):
     for p in (ROOT, os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
-    os.environ["FAKE_ENGINE_CYCLE"] = str(job.get("cycle", 8))
+    cyc = job.get("cycle", 8)      # one value, or one per rank (engines that disagree: see _agree_cycle)
+    os.environ["FAKE_ENGINE_CYCLE"] = str(cyc[rank] if isinstance(cyc, (list, tuple)) else cyc)
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -46,12 +47,16 @@ def worker(rank, world, port, job, outdir):
         if job.get("extent"):
             runner.engine.set_source_extent(*job["extent"])
         if job.get("options"):
-            runner.engine.set_option(**job["options"])
+            runner.set_option(**job["options"])
             assert runner.engine.cycle_steps == job["options"].get("max_pass_steps", 8)
         runner.upload(st["Ez"][r0:r1].astype(dtype), st["Hx"][r0:r1].astype(dtype),
                       st["Hy"][r0:min(r1, rows - 1)].astype(dtype))
         if job.get("probe"):
             runner.set_probe(job["probe"][0], job["probe"][1], sum(job["chunks"]))
+        if job.get("expect_cycle") is not None:
+            assert runner.cycle == job["expect_cycle"], (runner.cycle, job["expect_cycle"])
+        if job.get("expect_overlap") is not None:
+            assert runner.overlap == job["expect_overlap"], (rank, runner.overlap)
         done = 0
         for n in job["chunks"]:
             runner.run(n, job["src"][0], job["src"][1], st["amps"][done:done + n])

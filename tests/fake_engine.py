@@ -50,6 +50,11 @@ class FakeEngine:
     def set_stream(self, s):
         pass
 
+    def set_option(self, max_pass_steps=None, **_):
+        if max_pass_steps is not None:
+            self.cycle_steps = int(max_pass_steps)
+        return self
+
     def sync(self):
         pass
 

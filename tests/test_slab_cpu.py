@@ -102,3 +102,48 @@ def test_slab_runner_uniform_materials(tmp_path):
                  24, 11, amps=st["amps"])
     for a, b in zip(got, ref):
         assert np.array_equal(a, b)
+
+
+def _check(got, st, dtype, nsteps, src):
+    dt_ = np.dtype(dtype)
+    ref = [st[k].astype(dt_) for k in ("Ez", "Hx", "Hy")]
+    onp.leapfrog(*ref, st["eps"].astype(dt_), st["mu"].astype(dt_), DT, DX, nsteps, src[0], src[1],
+                 amps=st["amps"])
+    for a, b, k in zip(got, ref, ("Ez", "Hx", "Hy")):
+        assert a.shape == b.shape and np.array_equal(a, b), k
+
+
+@pytest.mark.parametrize("rows,overlapped", [(99, True), (98, False)])
+def test_three_ranks_agree_on_the_exchange_mode(tmp_path, rows, overlapped):
+    """99 rows = three 33-row slabs: every rank may overlap (2*16+1 rows).  98 rows = 33/33/32:
+    the short slab cannot, so NO rank does -- a per-rank decision would leave ranks 0 and 1 in the
+    overlapped cycle (send after the pass) and rank 2 in the plain one (send before it): deadlock."""
+    c, n = 18, 40
+    st, path = _state(str(tmp_path), rows, c, rows, n, vary_mu=True)
+    job = dict(engine="fake", shape=(rows, c), dtype="float32", dt=DT, dx=DX, state=path, src=(40, 5),
+               chunks=[32, 8], materials="array", overlap=True, cycle=16, expect_overlap=overlapped,
+               expect_cycle=16)
+    _check(run_job(3, job, str(tmp_path)), st, "float32", n, (40, 5))
+
+
+def test_ranks_whose_engines_disagree_use_the_shortest_cycle(tmp_path):
+    """An engine chooses 16- or 8-step passes from its own slab size; slabs differ by a row, so the
+    answers can differ.  The runner takes the minimum and hands it back to every engine."""
+    rows, c, n = 99, 16, 24
+    st, path = _state(str(tmp_path), rows, c, 3, n, vary_mu=True)
+    job = dict(engine="fake", shape=(rows, c), dtype="float32", dt=DT, dx=DX, state=path, src=(50, 4),
+               chunks=[24], materials="array", overlap=True, cycle=[16, 16, 8], expect_cycle=8)
+    _check(run_job(3, job, str(tmp_path)), st, "float32", n, (50, 4))
+
+
+@pytest.mark.parametrize("world,rows", [(4, 136), (8, 272), (8, 180)])
+def test_four_and_eight_slabs(tmp_path, world, rows):
+    """BASELINE configs 4 and 5 decompose into 4 and 8 slabs: interior ranks have two neighbours,
+    the source sits on a cut, 34-row slabs overlap (16-step cycles), 22-row slabs do not."""
+    c, n = 14, 35
+    st, path = _state(str(tmp_path), rows, c, world * rows, n, vary_mu=True)
+    src = (rows // 2, 6)
+    tall = rows // world >= 33
+    job = dict(engine="fake", shape=(rows, c), dtype="float32", dt=DT, dx=DX, state=path, src=src,
+               chunks=[16, 19], materials="array", overlap=True, cycle=16, expect_overlap=tall)
+    _check(run_job(world, job, str(tmp_path)), st, "float32", n, src)

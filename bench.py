@@ -174,12 +174,12 @@ def time_single(fd, rows, cols, steps, warmup, materials, device, boundary="mur"
     cyc = eng.cycle_steps
     res = dict(wall_s=wall, event_ms=ev_ms, pass_launches=eng.info(16) - l0[0],
                step_launches=eng.info(17) - l0[1], bpc=eng.bytes_per_cell_step, launch_steps=cyc,
-               band_rows=eng.info(19), waves_per_strip=eng.info(20))
+               band_rows=eng.info(19), waves_per_strip=eng.info(20), edge_rows=eng.info(21))
     # duration of the dominant kernel by itself: single full-length launches, each between its
     # own pair of HIP events on the engine's stream (what rocprofv3's kernel trace reports)
     if cyc:
         eng.run(cyc).sync()      # (also makes the full-length shape the "last" one when steps < cyc)
-        res["band_rows"], res["waves_per_strip"] = eng.info(19), eng.info(20)
+        res["band_rows"], res["waves_per_strip"], res["edge_rows"] = eng.last_shape
         one = np.sort(eng.time_launches(48, cyc))
         res["launch_ms"] = float(np.mean(one[4:-4]))       # trimmed mean of back-to-back launches
     Ez, _, _ = eng.download()
@@ -194,13 +194,13 @@ def pmc_child(args):
     """`bench.py --pmc-child`: a short steady-state sequence of full-length passes, run under
     `rocprofv3 --pmc ...` by measure_traffic().  Prints the launch shape it used."""
     import fdtd2d_amd as fd
-    shape = (args.band_rows, args.waves) if args.band_rows else None
+    shape = (args.band_rows, args.waves, args.edge_rows) if args.band_rows else None
     eng = make_engine(fd, args.grid, args.cols, args.materials, 0, args.boundary, shape)
     cyc = eng.cycle_steps
     n = cyc * 12
     eng.prepare(n)
     eng.run(n, args.grid // 2, args.cols // 2, amplitudes(fd, 0, n)).sync()
-    print(json.dumps({"pmc_child": True, "band_rows": eng.info(19), "waves": eng.info(20), "cycle": cyc}))
+    print(json.dumps({"pmc_child": True, "shape": list(eng.last_shape), "cycle": cyc}), flush=True)
     eng.close()
 
 
@@ -214,8 +214,6 @@ def _pmc_run(counters, child_args, timeout=240):
         cmd = [exe, "--pmc", *counters, "--kernel-trace", "--output-format", "csv", "-d", out, "--",
                sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child", *child_args]
         p = subprocess.run(cmd, cwd=out, capture_output=True, text=True, timeout=timeout)
-        if p.returncode != 0:
-            raise RuntimeError(f"rocprofv3 child failed ({p.returncode}): {p.stderr[-400:]}")
         info = None
         for line in p.stdout.splitlines():
             if line.startswith("{") and "pmc_child" in line:
@@ -225,7 +223,8 @@ def _pmc_run(counters, child_args, timeout=240):
             for r in csv.DictReader(open(f)):
                 acc.setdefault(r["Kernel_Name"], {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
         if info is None or not acc:
-            raise RuntimeError("rocprofv3 child produced no counters")
+            raise RuntimeError(f"rocprofv3 child produced no counters (exit code {p.returncode}): "
+                               f"{(p.stderr or p.stdout)[-300:]}")
         return acc, info
     finally:
         shutil.rmtree(out, ignore_errors=True)
@@ -255,8 +254,9 @@ def measure_traffic(rows, cols, materials, boundary):
         valu = _dominant(acc, "SQ_INSTS_VALU")[1]
     except RuntimeError:
         pass
-    shape = (int(info["band_rows"]), int(info["waves"]))
-    acc2, _ = _pmc_run(["WRITE_SIZE"], base + ["--band-rows", str(shape[0]), "--waves", str(shape[1])])
+    shape = tuple(int(v) for v in info["shape"])
+    acc2, _ = _pmc_run(["WRITE_SIZE"], base + ["--band-rows", str(shape[0]), "--waves", str(shape[1]),
+                                               "--edge-rows", str(shape[2])])
     _, write_kib = _dominant(acc2, "WRITE_SIZE")
     rd, wr = 2.0 * fetch_kib * 1024, write_kib * 1024      # gfx950: FETCH_SIZE tallies 128-B requests as 64 B
     return {"bytes_per_launch": int(rd + wr), "read": int(rd), "write": int(wr), "valu_insts": valu,
@@ -298,7 +298,8 @@ def roofline_block(cells, steps, r, traffic):
     out = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
            "traffic": None, "traffic_source": None, "overfetch": None, "valu_frac": None,
            "kernel": name, "steps_per_launch": spl,
-           "launch_shape": {"band_rows": r.get("band_rows"), "waves_per_strip": r.get("waves_per_strip")},
+           "launch_shape": {"band_rows": r.get("band_rows"), "waves_per_strip": r.get("waves_per_strip"),
+                            "edge_strip_band_rows": r.get("edge_rows")},
            "avg_launch_ms": round(ms, 5), "avg_launch_ms_incl_gaps": round(region_ms, 5),
            "steady_state_value": round(cells * spl / (ms * 1e-3) / 1e6, 1),
            "algorithmic": {"bytes_per_cell_step": r["bpc"], "bytes_per_launch": int(alg_bytes),
@@ -360,6 +361,7 @@ def main():
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--band-rows", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--waves", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--edge-rows", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     if args.pmc_child:

@@ -25,7 +25,7 @@ E_ARG, E_NODEVICE, E_NOMEM, E_STATE, E_COURANT = -1, -2, -3, -4, -5
 (INFO_ROWS, INFO_COLS, INFO_ROW0, INFO_NROWS, INFO_HALO, INFO_PITCH, INFO_DTYPE,
  INFO_BOUNDARY, INFO_DEVICE, INFO_EPS_UNIFORM, INFO_MU_UNIFORM, INFO_E_VALID_LO,
  INFO_E_VALID_HI, INFO_H_VALID_LO, INFO_H_VALID_HI, INFO_STEP, INFO_PASS_LAUNCHES,
- INFO_STEP_LAUNCHES, INFO_CYCLE_STEPS, INFO_LAST_BAND_ROWS, INFO_LAST_WAVES) = range(21)
+ INFO_STEP_LAUNCHES, INFO_CYCLE_STEPS, INFO_LAST_BAND_ROWS, INFO_LAST_WAVES, INFO_LAST_EDGE_ROWS) = range(22)
 
 _vp, _i, _d, _ll = C.c_void_p, C.c_int, C.c_double, C.c_longlong
 

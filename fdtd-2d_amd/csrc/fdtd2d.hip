@@ -51,10 +51,12 @@ double get_elem(const void *p, int dt, size_t i)
     return dt == FDTD2D_F64 ? ((const double *)p)[i] : (double)((const float *)p)[i];
 }
 
-// Field storage starts 64 B past a 128-B boundary: a strip of the 16-step pass begins HC = 16
-// columns left of a multiple of OW = 224 columns (896 B = 7 cache lines), so with this offset every
-// strip row is exactly 8 whole 128-B lines instead of 9 partly used ones.
-constexpr size_t FIELD_SHIFT = 64, FIELD_GUARD = 256;
+// Byte offset of a field's first element inside its allocation.  64 would put the strips of the
+// 16-step pass (which begin 16 columns left of a multiple of 224) on 128-B line boundaries; measured
+// on one box against 0, us per 16-step pass: 4096^2 157.0 vs 156.5, 8192^2 445.7 vs 444.0, 16384^2
+// 1510 vs 1483 (profiles/r02_field_shift.txt) -- the partly used lines are not what the 16384^2 pass
+// waits for, so the fields stay on the allocation's own alignment.
+constexpr size_t FIELD_SHIFT = 0, FIELD_GUARD = 256;
 
 int alloc_field(fdtd2d *h, void **p)
 {
@@ -662,6 +664,7 @@ long long fdtd2d_info(const fdtd2d_t *h, int what)
     case FDTD2D_INFO_CYCLE_STEPS: return h->cycle_steps();
     case FDTD2D_INFO_LAST_BAND_ROWS: return h->shape_last.band_rows;
     case FDTD2D_INFO_LAST_WAVES: return h->shape_last.waves;
+    case FDTD2D_INFO_LAST_EDGE_ROWS: return h->shape_last.edge_rows;
     default: return FDTD2D_E_ARG;
     }
 }
@@ -867,6 +870,40 @@ int fdtd2d_add_point(fdtd2d_t *h, int row, int col, double amp)
     return rc ? rc : do_add_point(h, row, col, amp);
 }
 
+// The next pass of a run with `rem` steps to go: kernel length *nt (the geometry: halo, strip
+// overlap, zone depth) and the levels *nlev <= *nt it advances.  Every pass is one sweep over the
+// grid whatever its length, so the plan minimises sweeps and never leaves a scrap: a remainder of
+// at most one pass runs on the shortest kernel that holds it (level-split kernels stop after nlev
+// levels; on very large grids a 24-step kernel takes 17..24 steps in one sweep), a remainder
+// between one and two passes is cut in halves, longer runs take full passes.  Returns false when
+// no temporally blocked pass is possible from the current state (small grids, an exhausted halo):
+// the caller then takes one plain step.
+static bool plan_pass(const fdtd2d *h, int rem, int *nt, int *nlev, int *lo, int *hi)
+{
+    const int C = h->cycle_steps();
+    if (C <= 0 || rem <= 0) return false;
+    const bool longp = C == 16 && h->long_passes();
+    int take = rem;
+    if (!(longp && rem <= 24)) {
+        if (rem > 2 * C) take = C;
+        else if (rem > C) take = (rem + 1) / 2;
+    }
+    const int lens[] = {1, 2, 4, 8, 16, 24};
+    auto avail = [&](int c) { return c <= C || (longp && c == 24); };
+    for (int c : lens)                      // shortest kernel that holds `take`
+        if (c >= take && avail(c) && pass_geometry(h, c, lo, hi) && (c == take || h->use_level_split(c, *lo, *hi))) {
+            *nt = c;
+            *nlev = take;
+            return true;
+        }
+    for (int k = 5; k >= 0; --k)            // else the longest full pass below it
+        if (lens[k] < take && avail(lens[k]) && pass_geometry(h, lens[k], lo, hi)) {
+            *nt = *nlev = lens[k];
+            return true;
+        }
+    return false;
+}
+
 // Measure the launch shape of a large pass once: trial launches write only into the buffers
 // the next committed pass overwrites anyway (commit = false), so the state is untouched.
 // Candidates: the rule of launch_pass, a ladder of band heights, and for 16-step passes both
@@ -880,12 +917,47 @@ static int tune_pass(fdtd2d *h, int nt, int lo, int hi, bool zt, bool zb)
         return 0;
     std::vector<fdtd2d::Shape> cand{{0, 0}};
     const bool split = h->use_level_split(nt, lo, hi);
-    const std::vector<int> ladder = nt == 16 ? std::vector<int>{64, 96, 144, 208, 304, 448}
+    const std::vector<int> ladder = nt >= 16 ? std::vector<int>{64, 96, 144, 208, 304, 448}
                                              : std::vector<int>{16, 24, 32, 48, 64, 96, 128};
+    const bool both_nw = split && nt == 16 && !h->split_waves;
     for (int nw : {4, 8}) {
-        if (nw == 8 && !(split && nt == 16 && !h->split_waves)) continue;
+        if (nw == 8 && !both_nw) continue;
         for (int br : ladder)
-            if (br * 4 <= hi - lo) cand.push_back({br, split && nt == 16 && !h->split_waves ? nw : 0});
+            if (br * 4 <= hi - lo) cand.push_back({br, both_nw ? nw : 0});
+    }
+    // Shapes that fill the GPU's workgroup slots in k whole rounds, with the first / last strip
+    // (~2x the work per row) cut into shorter bands: a launch lasts as long as its longest-lived
+    // workgroup, and one that needs 1.1 rounds lasts as long as two.  The zone tiles come first in
+    // launch order and hold a slot each.  (4096^2, us per 16-step pass: 64-row bands 158; 144-row
+    // bands with 32-row edge bands = 1021 workgroups for 1024 slots 147.5; 119 / 32 = 1123
+    // workgroups 184: profiles/r02_shape_sweep.txt)
+    if (split) {
+        const int region = hi - lo, V = h->dtype == FDTD2D_F32 ? 4 : 2;
+        const int ow = 64 * V - 2 * fdtd::stream_hc(nt);
+        const int ns = (h->cols + ow - 1) / ow;
+        const int zw = nt == 16 ? 30 : (nt == 8 ? 14 : 0);   // ZoneDims<NT>::WZ (24 steps: zones run beside the bulk)
+        const int zones = zw ? ((zt ? 1 : 0) + (zb ? 1 : 0)) * ((h->cols + zw - 1) / zw) : 0;
+        for (int nw : {4, 8}) {
+            if (nw == 8 && !both_nw) continue;
+            // resident workgroups (VGPR / LDS limits): 4 (3 at 24 steps) x 4 waves or 2 x 8 per CU
+            const int slots = 256 * (nw == 8 ? 2 : (nt == 24 ? 3 : 4));
+            const double fill = 2.0 * nt + nw - 1;
+            for (int k : {1, 2, 3, 4}) {
+                for (double w_e : {1.0, 2.0, 3.0}) {            // edge bands as tall, 1/2, 1/3 as long-lived
+                    const double tasks = (double)k * slots - (k == 1 ? zones : 0);
+                    fdtd2d::Shape best{0, 0};
+                    for (int nb = 1; nb <= region / 8; ++nb) {
+                        const double life = (double)region / nb + fill;      // ticks of a plain task
+                        const double er = life / w_e - fill;                   // rows of an equally long edge task
+                        const int ne = w_e == 1.0 ? nb : (er >= 8 ? (int)std::ceil(region / er) : region / 8);
+                        if ((double)std::max(0, ns - 2) * nb + 2.0 * ne > tasks) break;
+                        best = fdtd2d::Shape{(region + nb - 1) / nb, both_nw ? nw : 0,
+                                             w_e == 1.0 ? 0 : std::max(8, (region + ne - 1) / ne)};
+                    }
+                    if (best.band_rows >= 8) cand.push_back(best);
+                }
+            }
+        }
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
@@ -943,22 +1015,11 @@ int fdtd2d_prepare(fdtd2d_t *h, int nsteps)
     };
     int left = nsteps;
     while (left > 0 && rc == 0) {
-        int lo = 0, hi = 0;
-        const int L = (h->cycle_steps() == 16 && left < 8) ? 8 : h->cycle_steps();
-        if (L >= 8 && left < L && (left & (left - 1)) != 0 && pass_geometry(h, L, &lo, &hi) &&
-            h->use_level_split(L, lo, hi)) {
-            rc = warm(L, lo, hi, left);                     // the short tail pass
-            break;
-        }
-        int nt = 0;
-        for (int c : {16, 8, 4, 2, 1})
-            if (c <= left && (c != 16 || h->cycle_steps() == 16) && pass_geometry(h, c, &lo, &hi)) {
-                nt = c;
-                break;
-            }
-        if (!nt) break;                                     // single-step kernels: nothing to prepare
-        rc = nt >= 8 ? tune_pass(h, nt, lo, hi, h->top(), h->bottom()) : warm(nt, lo, hi, 0);
-        left %= nt;
+        int nt = 0, nlev = 0, lo = 0, hi = 0;
+        if (!plan_pass(h, left, &nt, &nlev, &lo, &hi)) break;      // single-step kernels: nothing to prepare
+        rc = (nt >= 8 && nlev == nt) ? tune_pass(h, nt, lo, hi, h->top(), h->bottom()) : warm(nt, lo, hi, nlev);
+        if (nlev == nt && left >= 2 * nt) left %= nt;               // the full passes of a long run are all alike
+        else left -= nlev;
     }
     if (rc) return rc;
     h->pass_launches = launches;
@@ -977,44 +1038,18 @@ int fdtd2d_run(fdtd2d_t *h, int nsteps, int src_row, int src_col, const double *
                     h->src_rows, h->src_cols, h->rows, h->cols);
     int n = 0;
     while (n < nsteps) {
-        // a tail that is not a power of two: ONE short pass on the longest kernel (each pass is a
-        // full sweep over the grid, whatever its length)
-        {
-            // (the levels are not re-balanced over the waves of a strip, so a short pass costs
-            // about a full pass of its kernel: tails below 8 take the 8-step kernel,
-            // profiles/r01_short_pass_cost.txt)
-            const int rem = nsteps - n, L = (h->cycle_steps() == 16 && rem < 8) ? 8 : h->cycle_steps();
-            int lo = 0, hi = 0;
-            if (L >= 8 && rem < L && (rem & (rem - 1)) != 0 && pass_geometry(h, L, &lo, &hi) &&
-                h->use_level_split(L, lo, hi)) {
-                // (no tune_pass here: a one-off tail does not pay for 20-120 ms of trial launches;
-                // the shape measured for full passes of this length is used if there is one)
-                h->probe_pending = h->probe_cap > 0;
-                const double *a = amps ? amps + n : nullptr;
-                rc = h->dtype == FDTD2D_F32
-                         ? launch_pass<float>(h, L, lo, hi, src_row, src_col, a, h->top(), h->bottom(), true, lo, hi, rem)
-                         : launch_pass<double>(h, L, lo, hi, src_row, src_col, a, h->top(), h->bottom(), true, lo, hi, rem);
-                if (rc) return rc;
-                n += rem;
-                continue;
-            }
-        }
-        // longest temporally blocked pass that fits, else one plain step
-        int nt = 0, lo = 0, hi = 0;
-        for (int c : {16, 8, 4, 2, 1})
-            if (c <= nsteps - n && (c != 16 || h->cycle_steps() == 16) && pass_geometry(h, c, &lo, &hi)) {
-                nt = c;
-                break;
-            }
-        if (nt) {
+        int nt = 0, nlev = 0, lo = 0, hi = 0;
+        if (plan_pass(h, nsteps - n, &nt, &nlev, &lo, &hi)) {
             const double *a = amps ? amps + n : nullptr;
-            if ((rc = tune_pass(h, nt, lo, hi, h->top(), h->bottom()))) return rc;
+            // (only full passes are tuned: a one-off tail does not pay for 20-120 ms of trial launches;
+            // it uses the shape measured for full passes of its kernel if there is one)
+            if (nlev == nt && (rc = tune_pass(h, nt, lo, hi, h->top(), h->bottom()))) return rc;
             h->probe_pending = h->probe_cap > 0;
             rc = h->dtype == FDTD2D_F32
-                     ? launch_pass<float>(h, nt, lo, hi, src_row, src_col, a, h->top(), h->bottom(), true, lo, hi)
-                     : launch_pass<double>(h, nt, lo, hi, src_row, src_col, a, h->top(), h->bottom(), true, lo, hi);
+                     ? launch_pass<float>(h, nt, lo, hi, src_row, src_col, a, h->top(), h->bottom(), true, lo, hi, nlev)
+                     : launch_pass<double>(h, nt, lo, hi, src_row, src_col, a, h->top(), h->bottom(), true, lo, hi, nlev);
             if (rc) return rc;
-            n += nt;
+            n += nlev;
             continue;
         }
         if ((rc = do_update_h(h))) return rc;
@@ -1134,7 +1169,7 @@ int fdtd2d_set_option(fdtd2d_t *h, int option, long long value)
     if (!h) return FDTD2D_E_ARG;
     switch (option) {
     case FDTD2D_OPT_MAX_PASS_STEPS:
-        if (value < 0 || value > fdtd::STREAM_MAX_NT) return fail(h, FDTD2D_E_ARG, "pass length must be 0..16");
+        if (value < 0 || value > fdtd::STREAM_MAX_NT) return fail(h, FDTD2D_E_ARG, "pass length must be 0..24");
         h->max_nt = (int)value;
         h->max_nt_forced = true;
         return 0;
@@ -1162,9 +1197,10 @@ int fdtd2d_set_option(fdtd2d_t *h, int option, long long value)
         h->tuned.clear();
         return 0;
     case FDTD2D_OPT_LONG_SHAPE: {
-        const int br = (int)(value & 0xffff), nw = (int)(value >> 16);
-        if (value < 0 || (nw != 0 && nw != 4 && nw != 8)) return fail(h, FDTD2D_E_ARG, "shape = band rows + 65536 * waves (0, 4 or 8)");
-        h->long_shape = fdtd2d::Shape{br, nw};
+        const int br = (int)(value & 0xffff), nw = (int)((value >> 16) & 0xffff), er = (int)((value >> 32) & 0xffff);
+        if (value < 0 || (nw != 0 && nw != 4 && nw != 8))
+            return fail(h, FDTD2D_E_ARG, "shape = band rows + 65536 * waves (0, 4 or 8) + 2^32 * edge band rows");
+        h->long_shape = fdtd2d::Shape{br, nw, er};
         return 0;
     }
     default: return fail(h, FDTD2D_E_ARG, "unknown option %d", option);

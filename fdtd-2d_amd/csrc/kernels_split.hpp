@@ -112,6 +112,15 @@ template <class T, bool GENERAL, bool CE_ARR, bool CH_ARR, int V> struct StripMa
     }
 };
 
+// Hand-off between the waves of a strip: wave w writes its finished row into its buffer of tick
+// parity tau & 1, waits for the writes, joins the barrier; wave w+1 reads it at the start of tick
+// tau + 1.  (Measured and rejected, profiles/r02_handoff_pipelining.txt: a 3-deep ring with the
+// reads prefetched one tick ahead and only the OLDER writes awaited before the barrier.  It takes
+// the LDS round trip out of every wave's tick but adds 2 ticks of fill per hand-off, and was 4-7 %
+// slower at 4096^2, 8192^2 and 16384^2: with 4 waves per SIMD the other waves already cover that
+// latency, the ticks run at ~95 % of the VALU issue rate those 4 waves can reach.)
+constexpr int HAND_DEPTH = 2;
+
 // ROLE 0: first wave (HBM -> LDS), 1: middle (LDS -> LDS), 2: last (LDS -> HBM)
 template <class T, int NT, int SPLIT_NW, bool CE_ARR, bool CH_ARR, bool GENERAL, int ROLE, int V>
 __device__ __forceinline__ void split_body(const PassParams<T> &p, const int strip, const int ra,
@@ -136,8 +145,15 @@ __device__ __forceinline__ void split_body(const PassParams<T> &p, const int str
     const int tend = rb + LV + (SPLIT_NW - 1) * LAG;              // ticks [tau0, tend) for every wave
     const int shift = w * LAG;                                    // this wave's input row = tau - shift
     const int t0 = w * LV;                                        // level of the input rows
-    // hand-off buffers: [hand-off h][parity][field][lane]
-    auto buf = [&](int h, int parity, int field) { return lds + ((h * 2 + parity) * NF + field) * 64 + lane; };
+    // Level t0 + l of this wave updates row r - l in the tick whose input row is r; it is inside the
+    // band's cone iff  r >= first[l]  and  r < r_end  (level t is needed on rows [ra-(NT-t)-1,
+    // rb+(NT-t)); r_end does not depend on l), and part of a short pass iff t0 + l <= nlev.
+    const int r_end = rb + NT - t0;
+    int first[LV + 1];
+#pragma unroll
+    for (int l = 1; l <= LV; ++l) first[l] = t0 + l <= p.nlev ? ra - NT + t0 + 2 * l - 1 : (1 << 30);
+    // hand-off ring: [hand-off h][slot d][field][lane]
+    auto buf = [&](int h, int d, int field) { return lds + ((h * HAND_DEPTH + d) * NF + field) * 64 + lane; };
 
     Row slot[S];
 #pragma unroll
@@ -169,6 +185,7 @@ __device__ __forceinline__ void split_body(const PassParams<T> &p, const int str
 #pragma unroll
         for (int k = 0; k < PF; ++k) load_global(slot[k], tau0 + k);
     }
+    // (the other waves start from the zeroed buffers: their first input rows are far above the cone)
 
     for (int tb = tau0; tb < tend; tb += S) {
 #pragma unroll
@@ -178,37 +195,39 @@ __device__ __forceinline__ void split_body(const PassParams<T> &p, const int str
             const int r = tau - shift;              // input row of this wave, level t0; lives in slot k
             if (ROLE == 0) {
                 load_global(slot[(k + PF) % S], r + PF);
-            } else {                                // row handed over by wave w-1 in the previous tick
-                const int par = (tau + 1) & 1;
-                slot[k].e = *buf(w - 1, par, 0);
-                slot[k].x = *buf(w - 1, par, 1);
-                slot[k].y = *buf(w - 1, par, 2);
-                if (CE_ARR) slot[k].ce = *buf(w - 1, par, 3);
-                if (CH_ARR) slot[k].ch = *buf(w - 1, par, NF - 1);
+            } else {                                // row r: written by wave w-1 in the previous tick
+                const int dr = (tau + 1) & 1;
+                Row &in = slot[k];
+                in.e = *buf(w - 1, dr, 0);
+                in.x = *buf(w - 1, dr, 1);
+                in.y = *buf(w - 1, dr, 2);
+                if (CE_ARR) in.ce = *buf(w - 1, dr, 3);
+                if (CH_ARR) in.ch = *buf(w - 1, dr, NF - 1);
             }
+            if (r < r_end) {
 #pragma unroll
-            for (int l = 1; l <= LV; ++l) {
-                const int t = t0 + l, i = r - l;
-                if (i < ra - (NT - t) - 1 || i >= rb + (NT - t) || t > p.nlev) continue;   // outside the cone / a short pass
-                Row &c = slot[(k - l + 2 * S) % S];
-                m.level(c, slot[(k - l + 1 + 2 * S) % S].e, slot[(k - l - 1 + 2 * S) % S].x, t, i);
+                for (int l = 1; l <= LV; ++l) {
+                    if (r < first[l]) continue;             // outside the cone / beyond a short pass
+                    Row &c = slot[(k - l + 2 * S) % S];
+                    m.level(c, slot[(k - l + 1 + 2 * S) % S].e, slot[(k - l - 1 + 2 * S) % S].x, t0 + l, r - l);
+                }
             }
             const Row &f = slot[(k - LV + 2 * S) % S];       // row r - LV, now at level t0 + LV
             if (ROLE == 2) {
                 const int io = r - LV;
                 const bool keep = st_ok && io >= ra && io < rb;
                 const size_t o = at(g, min(max(io, ra), rb - 1), 0) + col;
-                const size_t d = (size_t)(blockIdx.x % TRASH_SLOTS) * (TRASH_SLOT_BYTES / sizeof(T)) + (size_t)lane * V;
-                stn<V>(keep ? p.ez_out + o : p.trash + d, f.e);
-                stn<V>(keep ? p.hx_out + o : p.trash + d + 64 * V, f.x);
-                stn<V>(keep ? p.hy_out + o : p.trash + d + 128 * V, f.y);
+                const size_t dd = (size_t)(blockIdx.x % TRASH_SLOTS) * (TRASH_SLOT_BYTES / sizeof(T)) + (size_t)lane * V;
+                stn<V>(keep ? p.ez_out + o : p.trash + dd, f.e);
+                stn<V>(keep ? p.hx_out + o : p.trash + dd + 64 * V, f.x);
+                stn<V>(keep ? p.hy_out + o : p.trash + dd + 128 * V, f.y);
             } else {
-                const int par = tau & 1;
-                *buf(w, par, 0) = f.e;
-                *buf(w, par, 1) = f.x;
-                *buf(w, par, 2) = f.y;
-                if (CE_ARR) *buf(w, par, 3) = f.ce;
-                if (CH_ARR) *buf(w, par, NF - 1) = f.ch;
+                const int d = tau & 1;
+                *buf(w, d, 0) = f.e;
+                *buf(w, d, 1) = f.x;
+                *buf(w, d, 2) = f.y;
+                if (CE_ARR) *buf(w, d, 3) = f.ce;
+                if (CH_ARR) *buf(w, d, NF - 1) = f.ch;
             }
             __syncthreads();
         }
@@ -225,7 +244,7 @@ __global__ __launch_bounds__(64 * SPLIT_NW) void k_bulk_split(const PassParams<T
     constexpr int SW = 64 * V;
     constexpr int NF = 3 + (CE_ARR ? 1 : 0) + (CH_ARR ? 1 : 0);
     // one LDS allocation, used either as the hand-off buffers of a strip or as a zone tile
-    constexpr int HAND = (SPLIT_NW - 1) * 2 * NF * 64;                                  // VecN units
+    constexpr int HAND = (SPLIT_NW - 1) * HAND_DEPTH * NF * 64;                         // VecN units
     constexpr int ZONE = !FUSE ? 0 : (ZoneDims<NT>::LDS_ELEMS * (int)sizeof(T) + (int)sizeof(VecN<T, V>) - 1) /
                                          (int)sizeof(VecN<T, V>);
     __shared__ VecN<T, V> lds[HAND > ZONE ? HAND : ZONE];

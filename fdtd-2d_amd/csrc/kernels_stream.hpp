@@ -38,10 +38,10 @@ constexpr int PASS_THREADS = 256;    // threads per zone tile (4 waves share the
 // branched around.  One 4 KiB slot per workgroup (index mod 1024): a single shared line would
 // be written by every CU at once.
 constexpr int TRASH_SLOTS = 1024, TRASH_SLOT_BYTES = 4096;
-constexpr int STREAM_MAX_NT = 16;   // longest pass: 8 levels in one wave, 16 with the level-split kernel
+constexpr int STREAM_MAX_NT = 24;   // longest pass: 8 levels in one wave; 16 (4 or 8 waves) and 24 (8 waves x 3) with the level-split kernel
 // halo columns per strip side: >= NT (validity shrinks one column per level from a strip
 // edge) and a multiple of 4 so that every lane's 16-byte access stays aligned
-constexpr int stream_hc(int nt) { return nt <= 4 ? 4 : (nt <= 8 ? 8 : 16); }
+constexpr int stream_hc(int nt) { return nt <= 4 ? 4 : (nt <= 8 ? 8 : (nt <= 16 ? 16 : 24)); }
 
 template <class T> struct PassParams {
     const T *ez_in, *hx_in, *hy_in;
@@ -51,6 +51,8 @@ template <class T> struct PassParams {
     Geom g;
     int band_lo, band_hi;      // rows the streaming kernel produces
     int band_rows, nstrips, nbands;
+    int band_rows_e, nbands_e;   // shorter bands for the first / last strip (their GENERAL body is
+                               // ~2x slower per row: with equal heights they end a launch alone)
     int zone_top, zone_bot;    // 1 if this launch owns the grid's top / bottom zone
     int zone_tiles;            // column tiles per zone
     int fused_zones;           // 1: the zone tiles are the first workgroups of the k_bulk launch
@@ -130,11 +132,19 @@ __device__ __forceinline__ int strip_x0(const PassParams<T> &p, int strip)
 template <class T>
 __device__ __forceinline__ bool strip_of_block(const PassParams<T> &p, int b, int *strip, int *ra, int *rb)
 {
-    const int sidx = b / p.nbands, band = b - sidx * p.nbands;
-    if (sidx == 1 && p.nstrips == 1) return false;        // the second edge slot stays empty
-    *strip = sidx == 0 ? 0 : (sidx == 1 ? p.nstrips - 1 : sidx - 1);
-    *ra = p.band_lo + band * p.band_rows;
-    *rb = min(*ra + p.band_rows, p.band_hi);
+    if (b < 2 * p.nbands_e) {
+        const int sidx = b / p.nbands_e, band = b - sidx * p.nbands_e;
+        if (sidx == 1 && p.nstrips == 1) return false;    // the second edge slot stays empty
+        *strip = sidx == 0 ? 0 : p.nstrips - 1;
+        *ra = p.band_lo + band * p.band_rows_e;
+        *rb = min(*ra + p.band_rows_e, p.band_hi);
+    } else {
+        b -= 2 * p.nbands_e;
+        const int sidx = b / p.nbands, band = b - sidx * p.nbands;
+        *strip = sidx + 1;
+        *ra = p.band_lo + band * p.band_rows;
+        *rb = min(*ra + p.band_rows, p.band_hi);
+    }
     return *ra < *rb;
 }
 

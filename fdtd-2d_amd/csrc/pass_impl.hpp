@@ -11,19 +11,22 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
     using D = fdtd::ZoneDims<NT>;
     const int region = std::max(0, p.band_hi - p.band_lo);
     p.nbands = (region + p.band_rows - 1) / p.band_rows;
+    p.nbands_e = (region + p.band_rows_e - 1) / p.band_rows_e;
     p.zone_tiles = (h->cols + D::WZ - 1) / D::WZ;
     // launch order: zone tiles, 2 edge-strip slots (the second stays empty with one strip),
     // then strips 1 .. nstrips-2
-    const long long bulk = (long long)p.nbands * (2 + std::max(0, p.nstrips - 2));
+    const long long bulk = 2LL * p.nbands_e + (long long)p.nbands * std::max(0, p.nstrips - 2);
     const long long zones = (long long)(p.zone_top + p.zone_bot) * p.zone_tiles;
     if (bulk + zones == 0) return 0;
-    if constexpr (NT == 16 || NT == 8) {
+    if constexpr (NT >= 8) {
         if (h->use_level_split(NT, p.band_lo, p.band_hi)) {     // 4 waves per (band, strip), 2 levels each
             // zone tiles: the first workgroups of the same launch (default: saves the side-stream
             // launch and two cross-stream event waits per pass -- 38 vs 84 us per 8 steps at
             // 2048^2, 96 vs 99 at 4096^2, equal at 16384^2: profiles/r01_zone_fuse_split.txt) or
             // k_zone on the side stream (zone_split = 1)
-            const bool side = zones > 0 && h->zone_split == 1;
+            // (24-step passes: 4 waves x 6 levels at 3 workgroups per CU; a fused 54-row zone tile would
+            // take 56 KB of LDS from every workgroup and leave 2, so their zones always run as k_zone)
+            const bool side = zones > 0 && (h->zone_split == 1 || NT > 16);
             p.fused_zones = zones > 0 && !side;
             if (side) {
                 HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
@@ -39,8 +42,13 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
 #endif
             if (blocks > 0) {
                 // (array materials: one more row per slot and hand-off for each coefficient array)
-                const bool w8 = h->split_waves_for(NT, p.band_lo, p.band_hi) == 8;
-                const dim3 grid((unsigned)blocks), wg(w8 ? 512 : 256);
+                const int nw = h->split_waves_for(NT, p.band_lo, p.band_hi);
+                const dim3 grid((unsigned)blocks), wg(64 * nw);
+                if constexpr (NT > 16) {
+                    // 24 steps: 4 waves x 6 levels, zone tiles on the side stream
+                    hipLaunchKernelGGL((fdtd::k_bulk_split<T, NT, 4, false, CE_ARR, CH_ARR, V>), grid, wg, 0, h->stream, p);
+                } else {
+                const bool w8 = nw == 8;
                 // (a piece without zone tiles can run on either build; 8-step passes over array
                 // materials only have the fused one)
                 if (p.fused_zones || (!side && NT == 8 && (CE_ARR || CH_ARR))) {
@@ -52,6 +60,7 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
                 } else {
                     return fail(h, FDTD2D_E_STATE, "8-step level-split passes over array materials are built with fused zones only");
                 }
+                }
                 HIPCHK(h, hipGetLastError());
             }
             if (side) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
@@ -60,7 +69,7 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
         }
     }
     if constexpr (NT > 8) {
-        return fail(h, FDTD2D_E_ARG, "16-step passes run on the level-split kernel only");
+        return fail(h, FDTD2D_E_ARG, "16- to 24-step passes run on the level-split kernel only");
     } else {
     // Small launches: zone tiles as k_zone on the side stream (ordered behind what is already
     // on h->stream; everything later on h->stream waits for both).  Large launches: fused.
@@ -126,8 +135,9 @@ template <class T> int launch_probe(fdtd2d *h, int nt, const fdtd::PassParams<T>
     }
 }
 
-#ifdef FDTD_PASS_LONG_EXTERN   // the 16-step float32 kernels are built in pass_f32_long.hip
+#ifdef FDTD_PASS_LONG_EXTERN   // the 16- and 24-step float32 kernels are built in translation units of their own
 extern template int launch_pass_nt<float, 16>(fdtd2d *, fdtd::PassParams<float> &);
+extern template int launch_pass_nt<float, 24>(fdtd2d *, fdtd::PassParams<float> &);
 #endif
 
 // One pass of nt in {1,2,4,8,16} steps; amps = nt amplitudes or nullptr.
@@ -179,7 +189,7 @@ template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, 
         const int want = std::max(1, (slots + p.nstrips - 1) / p.nstrips);
         // 16-step passes: ~58 bands whatever the size is what tune_pass() keeps finding on square
         // grids (64 rows at 4096^2, 144 at 8192^2, 304 at 16384^2: profiles/r01_autotune.txt)
-        br = nt > 12 ? std::min(std::max((region + 57) / 58, 64), 448)
+        br = nt >= 16 ? std::min(std::max((region + 57) / 58, 64), 448)
                      : std::min(std::max(region / want, split4 ? 32 : 16), 128);
         // 8-step level-split passes: 1280 workgroups are resident at once (256 CUs x 5 at 93
         // VGPRs).  A launch of 1.0-1.6 times that leaves a thin second round; one round of taller
@@ -191,7 +201,9 @@ template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, 
         }
     }
     p.band_rows = std::max(br, 1);
-    h->shape_last = fdtd2d::Shape{p.band_rows, h->use_level_split(nt, band_lo, band_hi) ? h->split_waves_for(nt, band_lo, band_hi) : 1};
+    p.band_rows_e = h->shape_now.edge_rows > 0 ? h->shape_now.edge_rows : p.band_rows;
+    h->shape_last = fdtd2d::Shape{p.band_rows, h->use_level_split(nt, band_lo, band_hi) ? h->split_waves_for(nt, band_lo, band_hi) : 1,
+                                  p.band_rows_e};
     p.zone_top = ztop;
     p.zone_bot = zbot;
     p.trash = (T *)h->trash;
@@ -220,6 +232,7 @@ template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, 
         p.zone_tiles = 0;
         const int region = std::max(0, p.band_hi - p.band_lo);
         p.nbands = (region + p.band_rows - 1) / p.band_rows;
+        p.nbands_e = p.nbands;
         fdtd::PmlPass<T> q{pml_factors<T>(h), (const T *)h->ezxb[h->hcur], (T *)h->ezxb[h->hcur ^ 1],
                            0, 0, 0, 0, 0, 0, 0};
         // rows whose 8-step cone can touch the top / bottom layer: [0, L+1+16) and the mirror
@@ -245,6 +258,9 @@ template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, 
         rc = 0;
     } else
     switch (nt) {
+    case 24:
+        if constexpr (sizeof(T) == 4) { rc = launch_pass_nt<T, 24>(h, p); break; }
+        return fail(h, FDTD2D_E_ARG, "24-step passes are built for float32 only");
     case 16:
         if constexpr (sizeof(T) == 4) { rc = launch_pass_nt<T, 16>(h, p); break; }
         return fail(h, FDTD2D_E_ARG, "16-step passes are built for float32 only");

@@ -300,8 +300,9 @@ class Engine:
         if split_waves is not None:
             self._ck(self._lib.fdtd2d_set_option(self._h, _abi.OPT_SPLIT_WAVES, int(split_waves)))
         if long_shape is not None:       # (band rows, waves per strip) of the full-length passes
-            br, nw = long_shape
-            self._ck(self._lib.fdtd2d_set_option(self._h, _abi.OPT_LONG_SHAPE, int(br) + 65536 * int(nw)))
+            br, nw, *er = long_shape
+            self._ck(self._lib.fdtd2d_set_option(self._h, _abi.OPT_LONG_SHAPE,
+                                                 int(br) + 65536 * int(nw) + (int(er[0]) << 32 if er else 0)))
         return self
 
     def sync(self):
@@ -355,6 +356,11 @@ class Engine:
         out = (C.c_float * int(nlaunch))()
         self._ck(self._lib.fdtd2d_time_launches(self._h, int(nlaunch), int(steps_each), out))
         return np.array(out[:], dtype=np.float64)
+
+    @property
+    def last_shape(self):
+        """(band rows, waves per strip, band rows of the first / last strip) of the last pass."""
+        return self.info(_abi.INFO_LAST_BAND_ROWS), self.info(_abi.INFO_LAST_WAVES), self.info(_abi.INFO_LAST_EDGE_ROWS)
 
     @property
     def cycle_steps(self) -> int:

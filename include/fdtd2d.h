@@ -82,6 +82,7 @@ typedef struct fdtd2d fdtd2d_t;
 #define FDTD2D_INFO_STEP_LAUNCHES 17 /* single half-step kernels launched so far */
 #define FDTD2D_INFO_LAST_BAND_ROWS 19 /* band height of the last temporally blocked pass */
 #define FDTD2D_INFO_LAST_WAVES    20 /* its waves per (band, strip): 1 (k_bulk), 4 or 8 (k_bulk_split) */
+#define FDTD2D_INFO_LAST_EDGE_ROWS 21 /* its band height on the first / last strip */
 #define FDTD2D_INFO_CYCLE_STEPS   18 /* longest pass the current configuration runs: 16 (float32, Mur
                                          frame, >= 12 Mi cells per GPU), else 8, 0 if passes are off */
 
@@ -236,8 +237,9 @@ int fdtd2d_sync(fdtd2d_t *h);
                                          with uncommitted trial launches and keeps the fastest;
                                          0: fixed rules.  Results are identical either way. */
 #define FDTD2D_OPT_LONG_SHAPE      6   /* launch shape of the full-length passes (16 or 8 steps), value =
-                                         band rows + 65536 * waves per strip (0 = automatic): re-use a
-                                         shape the tuner found in another process; 0 clears it */
+                                         band rows + 65536 * waves per strip (0 = automatic) + 2^32 * band
+                                         rows of the first / last strip (0 = the same): re-use a shape
+                                         the tuner found in another process; 0 clears it */
 int fdtd2d_set_option(fdtd2d_t *h, int option, long long value);
 
 /* ---- row-slab halo exchange (transport is the caller's: RCCL via torch.distributed) -- */

@@ -587,6 +587,31 @@ def test_short_tail_passes_match_oracle(fd, onp, tag, dtype, n, kind):
     assert np.array_equal(series, np.array(want))
 
 
+@pytest.mark.parametrize("kind", ["uniform", "eps", "eps+mu"])
+@pytest.mark.parametrize("n,passes", [(17, 1), (20, 1), (21, 1), (24, 1), (40, 2), (41, 3), (49, 3), (65, 4)])
+def test_24_step_passes_match_oracle(fd, onp, n, passes, kind):
+    """A remainder of 17..24 steps runs as ONE pass on the 24-step kernel (4 waves x 6 levels, 29-row
+    zones as k_zone, 24-column strip overlap), stopping after n levels; longer runs take 16-step
+    passes first (40 = 16 + 24, 41 = 16 + 13 + 12).  The size rule is lifted by max_pass_steps=24.
+    Source rectangle on the corner of a zone, fields from a random state, float32; value-identical."""
+    r, c = 150, 700
+    rng = np.random.default_rng(1000 + n)
+    Ez, Hx, Hy, eps, mu = _random_state(rng, r, c, np.float32, onp, vary_mu=(kind == "eps+mu"))
+    if kind == "uniform":
+        eps = np.full((r, c), 2.3 * onp.EPS0, np.float32)
+    amps = rng.standard_normal(n)
+    ref = [a.copy() for a in (Ez, Hx, Hy)]
+    onp.leapfrog(*ref, eps, mu, DT, DX, n, 24, 228, amps=amps, extent=(3, 2))
+    with fd.Engine(r, c, DT, DX, dtype=np.float32) as eng:
+        eng.set_materials(eps, mu).set_option(max_pass_steps=24, band_rows=40).set_source_extent(3, 2)
+        eng.upload(Ez, Hx, Hy)
+        eng.run(n, 24, 228, amps)
+        got = eng.download()
+        assert eng.step_count == n and eng.info(16) == passes
+    for a, b, k in zip(got, ref, ("Ez", "Hx", "Hy")):
+        assert np.array_equal(a, b), f"{k} n={n} {kind}: {np.argwhere(a != b)[:4]}"
+
+
 @pytest.mark.parametrize("split_waves", [4, 8])
 @pytest.mark.parametrize("shape", [(76, 64), (100, 225), (130, 470), (200, 1000)])
 @pytest.mark.parametrize("src", [(0, 0), (20, 30), (21, 223), (60, 100)])

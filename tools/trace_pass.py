@@ -25,18 +25,23 @@ with fd.Engine(g, g, dtype=np.float32) as e:
     e.set_materials()
     if br:
         e.set_option(long_shape=(br, nw))
-    e.prepare(64)
-    e.run(64)
-    ms = np.sort(e.time_launches(16, 16))
+    N = int(os.environ.get("TRACE_N", "16"))      # pass length to look at (16, 20 or 24)
+    e.prepare(N)
+    e.run(N * 4)
+    ms = np.sort(e.time_launches(16, N))
     e.sync()
     shape = (e.info(19), e.info(20))
 t = np.loadtxt(path, dtype=np.uint64).reshape(-1, 5)
 os.remove(path)
 t0, t1, kind, hw = t[:, 1].astype(np.int64), t[:, 2].astype(np.int64), t[:, 3].astype(int), t[:, 4].astype(np.int64)
-base = t0.min()
-t0, t1 = t0 - base, t1 - base
+xcc = hw >> 16
+for x in np.unique(xcc):        # s_memtime is a per-XCD counter: align every XCD at its first workgroup
+    m = xcc == x
+    base = t0[m].min()
+    t0[m] -= base
+    t1[m] -= base
 span = t1.max()
-print(f"{g}x{g}: shape (band rows, waves) = {shape}, launch {np.median(ms) * 1e3:.1f} us by HIP events, "
+print(f"{g}x{g} run({os.environ.get('TRACE_N', '16')}): shape (band rows, waves) = {shape}, launch {np.median(ms) * 1e3:.1f} us by HIP events, "
       f"{len(t)} workgroups, span {span} cycles ({span / (np.median(ms) * 1e3):.0f} cycles/us)")
 for k, name in ((0, "zone tiles"), (1, "edge strips"), (2, "plain strips")):
     m = kind == k
@@ -50,7 +55,6 @@ res = [int(((t0 <= x) & (t1 > x)).sum()) for x in ts]
 print("  resident workgroups at 0,5,..100 % of the span:", res)
 busy = (t1 - t0).sum()
 print(f"  sum of lifetimes / (span x 1024 slots) = {busy / (span * 1024.0):.3f}")
-xcc = hw >> 16
 cu = ((hw >> 8) & 0xf) + 16 * ((hw >> 13) & 0x7) + 128 * ((hw >> 12) & 1)
 per = {}
 for x, c, a, b in zip(xcc, cu, t0, t1):

@@ -62,6 +62,11 @@ SIGNATURES = {
     "fdtd2d_halo_bytes": (_ll, [_vp]),
     "fdtd2d_halo_pack": (_i, [_vp, _i, _vp]),
     "fdtd2d_halo_unpack": (_i, [_vp, _i, _vp]),
+    "fdtd2d_slab_attach": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fdtd2d_rccl_unique_id": (_i, [_vp]),
+    "fdtd2d_slab_attach_rccl": (_i, [_vp, _vp, _i, _i]),
+    "fdtd2d_slab_detach": (_i, [_vp]),
+    "fdtd2d_run_slab": (_i, [_vp, _i, _i, _i, _i, _i, C.POINTER(_d)]),
     "fdtd2d_snapshot_index": (_i, [_vp, _d, _d, _i, _vp]),
     "fdtd2d_reduce": (_i, [_vp, _i, C.POINTER(_d), C.POINTER(_d)]),
     "fdtd2d_timer_start": (_i, [_vp]),
@@ -71,6 +76,9 @@ SIGNATURES = {
     "fdtd2d_device_ptr": (_vp, [_vp, _i]),
     "fdtd2d_version": (C.c_char_p, []),
 }
+
+# transport callback of fdtd2d_slab_attach
+EXCHANGE_FN = C.CFUNCTYPE(_i, _vp, _vp, _vp, _vp, _vp, _ll, _vp)
 
 _lib = None
 

@@ -18,6 +18,7 @@
 #include "kernels_stream.hpp"
 #include "kernels_pml.hpp"
 #include "kernels_split.hpp"
+#include "kernels_pml_split.hpp"
 #include "kernels_probe.hpp"
 
 using fdtd::Geom;
@@ -46,7 +47,8 @@ struct fdtd2d {
     void *pml = nullptr;                  // PML only: 4 row + 4 column factor arrays, back to back
     bool have_pml = false;
     int pml_L = 0;
-    int pml_short_rows = 16;     // band height of the layer waves
+    int pml_short_rows = 16;     // band height of the layer waves (8-step k_pass_pml)
+    int pml_layer_rows = 64;     // band height of the layer workgroups (16-step k_bulk_split_pml)
     int nfields() const { return boundary == FDTD2D_BOUNDARY_PML ? 4 : 3; }
     bool have_mat = false, ce_uniform = true, ch_uniform = true;
     double ce_u = 0, ch_u = 0;   // uniform coefficients, already rounded to T
@@ -103,6 +105,11 @@ struct fdtd2d {
         if (dtype != FDTD2D_F32 || boundary != FDTD2D_BOUNDARY_MUR5 || max_nt < 24 || probe_cap) return false;
         return max_nt_forced || (size_t)nrows * cols >= (size_t)128 << 20;
     }
+    // 16-step PML passes: the level-split pair k_bulk_split / k_bulk_split_pml (float32, uniform mu)
+    bool pml_split(int nt) const
+    {
+        return boundary == FDTD2D_BOUNDARY_PML && nt == 16 && dtype == FDTD2D_F32 && ch_uniform && have_pml;
+    }
     bool use_level_split(int nt, int band_lo, int band_hi) const
     {
         (void)band_lo, (void)band_hi;
@@ -147,7 +154,7 @@ struct fdtd2d {
         // (profiles/r01_nt16_sweep.txt)
         const bool big = (size_t)nrows * cols >= (size_t)12 << 20;
         if (max_nt >= 16 && (big || max_nt_forced) && dtype == FDTD2D_F32 && have_mat &&
-            boundary == FDTD2D_BOUNDARY_MUR5)
+            (boundary == FDTD2D_BOUNDARY_MUR5 || (boundary == FDTD2D_BOUNDARY_PML && ch_uniform)))
             return 16;
         return std::min(max_nt, 8);
     }
@@ -196,6 +203,8 @@ template <class T>
 int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, int src_row, int src_col,
                 const double *amps, bool ztop, bool zbot, bool commit, int full_lo, int full_hi,
                 int nlev = 0);
+// the 16-step PML pass (pass_f32_pml.hip): k_bulk_split on the cells clear of the layer, k_bulk_split_pml on the rest
+int launch_pml_split_f32(fdtd2d *h, fdtd::PassParams<float> &p);
 extern template int launch_pass<float>(fdtd2d *, int, int, int, int, int, const double *, bool, bool, bool, int, int, int);
 extern template int launch_pass<double>(fdtd2d *, int, int, int, int, int, const double *, bool, bool, bool, int, int, int);
 

@@ -354,8 +354,9 @@ bool pass_geometry(const fdtd2d *h, int nt, int *band_lo, int *band_hi)
     if (h->probe_cap && h->boundary == FDTD2D_BOUNDARY_PML)
         return false;          // no probe tile for these: the run falls back to shorter passes / single steps
     if (h->boundary == FDTD2D_BOUNDARY_PML) {
-        // k_pass_pml: 8-step passes, uniform mu, bands over all rows (no zones)
-        if (nt != 8 || nt > h->max_nt || !h->ch_uniform || !h->have_pml) return false;
+        // k_pass_pml: 8-step passes; k_bulk_split + k_bulk_split_pml: 16 steps (float32); uniform mu,
+        // bands over all rows (no zones)
+        if ((nt != 8 && !h->pml_split(nt)) || nt > h->max_nt || !h->ch_uniform || !h->have_pml) return false;
         if (h->rows < 64 || h->cols < 64) return false;
         const int a = std::max(h->ev.lo, h->hv.lo), b = std::min(h->ev.hi, h->hv.hi);
         const int lo = h->top() ? 0 : a + nt, hi = h->bottom() ? h->rows : b - nt;
@@ -618,6 +619,7 @@ int fdtd2d_create_slab(fdtd2d_t **out, int rows, int cols, int row0, int nrows, 
 void fdtd2d_destroy(fdtd2d_t *h)
 {
     if (!h) return;
+    (void)fdtd2d_slab_detach(h);
     if (hipSetDevice(h->device) == hipSuccess) {
         if (h->stream && h->stream != h->own_stream) (void)hipStreamSynchronize(h->stream);
         if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
@@ -891,7 +893,8 @@ static bool plan_pass(const fdtd2d *h, int rem, int *nt, int *nlev, int *lo, int
     const int lens[] = {1, 2, 4, 8, 16, 24};
     auto avail = [&](int c) { return c <= C || (longp && c == 24); };
     for (int c : lens)                      // shortest kernel that holds `take`
-        if (c >= take && avail(c) && pass_geometry(h, c, lo, hi) && (c == take || h->use_level_split(c, *lo, *hi))) {
+        if (c >= take && avail(c) && pass_geometry(h, c, lo, hi) &&
+            (c == take || h->use_level_split(c, *lo, *hi) || h->pml_split(c))) {
             *nt = c;
             *nlev = take;
             return true;
@@ -1017,7 +1020,8 @@ int fdtd2d_prepare(fdtd2d_t *h, int nsteps)
     while (left > 0 && rc == 0) {
         int nt = 0, nlev = 0, lo = 0, hi = 0;
         if (!plan_pass(h, left, &nt, &nlev, &lo, &hi)) break;      // single-step kernels: nothing to prepare
-        rc = (nt >= 8 && nlev == nt) ? tune_pass(h, nt, lo, hi, h->top(), h->bottom()) : warm(nt, lo, hi, nlev);
+        rc = (nt >= 8 && nlev == nt && h->boundary == FDTD2D_BOUNDARY_MUR5) ? tune_pass(h, nt, lo, hi, h->top(), h->bottom())
+                                                                            : warm(nt, lo, hi, nlev);
         if (nlev == nt && left >= 2 * nt) left %= nt;               // the full passes of a long run are all alike
         else left -= nlev;
     }

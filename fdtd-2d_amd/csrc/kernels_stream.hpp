@@ -53,6 +53,11 @@ template <class T> struct PassParams {
     int band_rows, nstrips, nbands;
     int band_rows_e, nbands_e;   // shorter bands for the first / last strip (their GENERAL body is
                                // ~2x slower per row: with equal heights they end a launch alone)
+    int strip_first;           // first strip of the "inner" set (1; the PML pass gives its layer strips
+                               // to another kernel and sets nbands_e = 0)
+    int src_strip, n_src;      // inner strips [src_strip, src_strip + n_src) hold the source columns: their
+                               // workgroups near the source rows run the GENERAL body too, so they get the
+                               // short bands of the edge strips (n_src = 0: no such strips)
     int zone_top, zone_bot;    // 1 if this launch owns the grid's top / bottom zone
     int zone_tiles;            // column tiles per zone
     int fused_zones;           // 1: the zone tiles are the first workgroups of the k_bulk launch
@@ -132,16 +137,18 @@ __device__ __forceinline__ int strip_x0(const PassParams<T> &p, int strip)
 template <class T>
 __device__ __forceinline__ bool strip_of_block(const PassParams<T> &p, int b, int *strip, int *ra, int *rb)
 {
-    if (b < 2 * p.nbands_e) {
+    if (b < (2 + p.n_src) * p.nbands_e) {
         const int sidx = b / p.nbands_e, band = b - sidx * p.nbands_e;
         if (sidx == 1 && p.nstrips == 1) return false;    // the second edge slot stays empty
-        *strip = sidx == 0 ? 0 : p.nstrips - 1;
+        *strip = sidx == 0 ? 0 : (sidx == 1 ? p.nstrips - 1 : p.src_strip + sidx - 2);
         *ra = p.band_lo + band * p.band_rows_e;
         *rb = min(*ra + p.band_rows_e, p.band_hi);
     } else {
-        b -= 2 * p.nbands_e;
+        b -= (2 + p.n_src) * p.nbands_e;
         const int sidx = b / p.nbands, band = b - sidx * p.nbands;
-        *strip = sidx + 1;
+        int st = sidx + p.strip_first;
+        if (p.n_src > 0 && st >= p.src_strip) st += p.n_src;      // the source strips were dealt with above
+        *strip = st;
         *ra = p.band_lo + band * p.band_rows;
         *rb = min(*ra + p.band_rows, p.band_hi);
     }

@@ -1,0 +1,70 @@
+// float32 16-step passes with the split-field PML: host side + kernel instantiations.
+#include "engine.hpp"
+
+namespace fdtd_host {
+
+template <bool CE_ARR> static int launch_pml_split(fdtd2d *h, fdtd::PassParams<float> &p)
+{
+    using T = float;
+    constexpr int NT = 16, NW = 4, V = 4, SW = 64 * V, HC = fdtd::stream_hc(NT), OW = SW - 2 * HC;
+    const int L = h->pml_L, R = h->rows, C = h->cols, ns = p.nstrips;
+    const int region = std::max(0, p.band_hi - p.band_lo);
+    if (region == 0) return 0;
+    auto x0_of = [&](int s) {
+        int x = s * OW - HC;
+        if (s == ns - 1) x = std::min(x, (C - SW + 3) & ~3);
+        return x;
+    };
+    // strips whose columns reach into the layer (or the grid edge) at either end
+    int n_left = 0, n_right = 0;
+    while (n_left < ns && x0_of(n_left) < L + 1) ++n_left;
+    while (n_right < ns - n_left && x0_of(ns - 1 - n_right) + SW > C - 1 - L) ++n_right;
+    const int inner = ns - n_left - n_right;
+    // rows whose 16-step cone can touch the top / bottom layer: [0, L + 1 + 2 NT) and the mirror
+    const int reach = L + 1 + 2 * NT, re = std::max(16, h->pml_layer_rows);
+    auto up = [&](int x) { return (x + re - 1) / re * re; };
+    int a_hi = p.band_lo, c_lo = p.band_hi;
+    if (inner > 0) {
+        if (h->top()) a_hi = std::min(p.band_hi, p.band_lo + up(std::max(0, reach - p.band_lo)));
+        if (h->bottom()) c_lo = std::max(a_hi, p.band_hi - up(std::max(0, p.band_hi - (R - reach))));
+    }
+    fdtd::PmlSplit<T> q{pml_factors<T>(h), (const T *)h->ezxb[h->hcur], (T *)h->ezxb[h->hcur ^ 1],
+                        n_left, n_right, re, a_hi, c_lo, (region + re - 1) / re,
+                        (a_hi - p.band_lo + re - 1) / re, (p.band_hi - c_lo + re - 1) / re};
+    const long long layer_blocks = (long long)(n_left + n_right) * q.n_all + (long long)inner * (q.n_top + q.n_bot);
+    // the plain kernel: inner strips x the rows between the layer bands, no edge strips, no zones
+    fdtd::PassParams<T> pp = p;
+    pp.band_lo = a_hi;
+    pp.band_hi = c_lo;
+    pp.strip_first = n_left;
+    pp.nbands_e = 0;
+    pp.band_rows_e = pp.band_rows;
+    pp.nbands = (std::max(0, c_lo - a_hi) + pp.band_rows - 1) / pp.band_rows;
+    const long long plain_blocks = (long long)pp.nbands * inner;
+    const bool both = layer_blocks > 0 && plain_blocks > 0;
+    if (both) {
+        HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
+        HIPCHK(h, hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
+    }
+    if (layer_blocks > 0) {          // the slower workgroups: started first, beside the plain kernel
+        hipLaunchKernelGGL((fdtd::k_bulk_split_pml<T, NT, NW, CE_ARR, V>), dim3((unsigned)layer_blocks), dim3(64 * NW), 0,
+                           both ? h->side_stream : h->stream, p, q);
+        HIPCHK(h, hipGetLastError());
+    }
+    if (both) HIPCHK(h, hipEventRecord(h->ev_join, h->side_stream));
+    if (plain_blocks > 0) {
+        hipLaunchKernelGGL((fdtd::k_bulk_split<T, NT, NW, false, CE_ARR, false, V>), dim3((unsigned)plain_blocks), dim3(64 * NW), 0,
+                           h->stream, pp);
+        HIPCHK(h, hipGetLastError());
+    }
+    if (both) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
+    h->pass_launches++;
+    return 0;
+}
+
+int launch_pml_split_f32(fdtd2d *h, fdtd::PassParams<float> &p)
+{
+    return h->ce_uniform ? launch_pml_split<false>(h, p) : launch_pml_split<true>(h, p);
+}
+
+}  // namespace fdtd_host

@@ -12,10 +12,28 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
     const int region = std::max(0, p.band_hi - p.band_lo);
     p.nbands = (region + p.band_rows - 1) / p.band_rows;
     p.nbands_e = (region + p.band_rows_e - 1) / p.band_rows_e;
+    // inner strips that hold source columns (at most two neighbours; wider sources get no special bands)
+    p.src_strip = 0;
+    p.n_src = 0;
+    if (p.src_col1 > p.src_col && p.band_rows_e < p.band_rows && p.nstrips > 2) {
+        constexpr int SWc = 64 * V, OWc = SWc - 2 * fdtd::stream_hc(NT);
+        int s0 = -1, s1 = -1;
+        for (int st = 1; st <= p.nstrips - 2; ++st) {
+            const int x0 = st * OWc - fdtd::stream_hc(NT);
+            if (p.src_col1 > x0 && p.src_col < x0 + SWc) {
+                if (s0 < 0) s0 = st;
+                s1 = st;
+            }
+        }
+        if (s0 >= 0 && s1 - s0 + 1 <= 2) {
+            p.src_strip = s0;
+            p.n_src = s1 - s0 + 1;
+        }
+    }
     p.zone_tiles = (h->cols + D::WZ - 1) / D::WZ;
     // launch order: zone tiles, 2 edge-strip slots (the second stays empty with one strip),
     // then strips 1 .. nstrips-2
-    const long long bulk = 2LL * p.nbands_e + (long long)p.nbands * std::max(0, p.nstrips - 2);
+    const long long bulk = (2LL + p.n_src) * p.nbands_e + (long long)p.nbands * std::max(0, p.nstrips - 2 - p.n_src);
     const long long zones = (long long)(p.zone_top + p.zone_bot) * p.zone_tiles;
     if (bulk + zones == 0) return 0;
     if constexpr (NT >= 8) {
@@ -214,9 +232,11 @@ template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, 
     p.src_col1 = amps ? src_col + h->src_cols : NONE;
     // a short pass: the nt-step kernel and geometry, advancing only nlev < nt levels (one sweep
     // over the grid for a tail of 3, 5, 6, 7, 9..15 steps instead of one per power of two)
+    p.strip_first = 1;
+    p.src_strip = p.n_src = 0;
     p.nlev = nlev > 0 ? std::min(nlev, nt) : nt;
-    if (p.nlev != nt && !h->use_level_split(nt, band_lo, band_hi))
-        return fail(h, FDTD2D_E_ARG, "short passes run on the level-split kernel only");
+    if (p.nlev != nt && !h->use_level_split(nt, band_lo, band_hi) && !h->pml_split(nt))
+        return fail(h, FDTD2D_E_ARG, "short passes run on the level-split kernels only");
     for (int s = 0; s < fdtd::STREAM_MAX_NT; ++s) p.amp[s] = (amps && s < p.nlev) ? amps[s] : 0.0;
 #ifdef FDTD2D_TRACE
     p.trace = (unsigned long long *)h->trace_dev;
@@ -227,7 +247,13 @@ template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, 
         h->probe_pending = false;
         if ((rc = launch_probe<T>(h, nt, p))) return rc;
     }
-    if (h->boundary == FDTD2D_BOUNDARY_PML) {
+    if (h->boundary == FDTD2D_BOUNDARY_PML && h->pml_split(nt)) {
+        p.zone_top = p.zone_bot = 0;
+        p.zone_tiles = 0;
+        p.fused_zones = 0;
+        if constexpr (sizeof(T) == 4) rc = launch_pml_split_f32(h, p);
+        else return fail(h, FDTD2D_E_ARG, "16-step PML passes are built for float32 only");
+    } else if (h->boundary == FDTD2D_BOUNDARY_PML) {
         p.zone_top = p.zone_bot = 0;
         p.zone_tiles = 0;
         const int region = std::max(0, p.band_hi - p.band_lo);

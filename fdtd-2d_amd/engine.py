@@ -323,6 +323,49 @@ class Engine:
     def halo_unpack(self, side: int, dev_ptr: int):
         self._ck(self._lib.fdtd2d_halo_unpack(self._h, int(side), dev_ptr))
 
+    # -- the slab loop in C (fdtd2d_run_slab): no Python per exchange cycle ------------------------
+    def slab_attach(self, bufs, fn):
+        """bufs: {side: (send_ptr, recv_ptr)} device pointers of fdtd2d_halo_bytes each (side 0 = top
+        neighbour, 1 = bottom); fn(send_top, recv_top, send_bottom, recv_bottom, nbytes, stream) is
+        the transport (pointers are None for a side without neighbour), returning 0."""
+        def cb(_ctx, st, rt, sb, rb, nbytes, stream):
+            try:
+                return int(fn(st, rt, sb, rb, int(nbytes), stream) or 0)
+            except Exception:            # never unwind through the C frame
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._exchange_cb = _abi.EXCHANGE_FN(cb)         # keep the thunk alive as long as the handle
+        g = lambda side, k: bufs[side][k] if side in bufs else None
+        self._ck(self._lib.fdtd2d_slab_attach(self._h, g(0, 0), g(0, 1), g(1, 0), g(1, 1),
+                                              C.cast(self._exchange_cb, C.c_void_p), None))
+        return self
+
+    def slab_attach_rccl(self, unique_id: bytes, rank: int, world: int):
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        self._ck(self._lib.fdtd2d_slab_attach_rccl(self._h, buf, int(rank), int(world)))
+        return self
+
+    @staticmethod
+    def rccl_unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        lib = _abi.load()
+        rc = lib.fdtd2d_rccl_unique_id(buf)
+        if rc:
+            raise _abi.Fdtd2dError(rc, lib.fdtd2d_last_error(None).decode())
+        return buf.raw
+
+    def run_slab(self, nsteps, cycle, overlap, src_row=0, src_col=0, amps=None):
+        ap = None
+        if amps is not None:
+            a = np.ascontiguousarray(amps, dtype=np.float64)
+            if a.shape[0] < nsteps:
+                raise ValueError("amps shorter than nsteps")
+            ap = a.ctypes.data_as(C.POINTER(C.c_double))
+        self._ck(self._lib.fdtd2d_run_slab(self._h, int(nsteps), int(cycle), int(bool(overlap)), int(src_row),
+                                           int(src_col), ap))
+        return self
+
     # -- consumers of the fields next to the loop ---------------------------------------------
     def snapshot_index(self, vmin, vmax, stride=1):
         """uint8 colour-map indices of Ez (owned rows whose global index is a multiple of

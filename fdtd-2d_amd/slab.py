@@ -66,7 +66,7 @@ class SlabRunner:
     per-rank engine (default: the HIP Engine)."""
 
     def __init__(self, rows, cols, dt=5e-14, dx=1e-4, dtype=np.float32, boundary="mur", device=0,
-                 halo=None, group=None, engine_factory=None, overlap=True):
+                 halo=None, group=None, engine_factory=None, overlap=True, loop="auto"):
         import torch
         import torch.distributed as dist
         self.dist, self.torch = dist, torch
@@ -123,6 +123,31 @@ class SlabRunner:
                     stage = (torch.empty(n, dtype=td).pin_memory(), torch.empty(n, dtype=td).pin_memory())
                 self._bufs[side] = (send, recv, stage)
         self.steps_done = 0
+        # loop = "c": the whole run is enqueued by ONE call into the library (fdtd2d_run_slab) -- with
+        # the "nccl" backend through the library's own RCCL point-to-point transport (communicator
+        # created from an id broadcast here), with gloo through a callback that stages the messages
+        # through the host (tests).  loop = "python": the cycle is sequenced below, call by call, with
+        # torch.distributed as the transport.  "auto" = "c" on nccl where the engine offers it.
+        if loop == "auto":
+            loop = "c" if (self.backend == "nccl" and hasattr(self.engine, "run_slab")) else "python"
+        self.loop = loop if self.world > 1 else "python"
+        if self.loop == "c":
+            if self.backend == "nccl":
+                uid = torch.zeros(128, dtype=torch.uint8)
+                if self.rank == 0:
+                    uid = torch.frombuffer(bytearray(self.engine.rccl_unique_id()), dtype=torch.uint8).clone()
+                uid = self._host_collective(uid, lambda t: dist.broadcast(t, src=self._global(0), group=self.group))
+                self.engine.slab_attach_rccl(bytes(uid.numpy().tobytes()), self.rank, self.world)
+            else:
+                self.engine.slab_attach({s: (b[0].data_ptr(), b[1].data_ptr()) for s, b in self._bufs.items()},
+                                        self._c_transport)
+
+    def _c_transport(self, send_top, recv_top, send_bottom, recv_bottom, nbytes, stream):
+        """Transport callback of the C loop for backends that move host memory (gloo): blocking."""
+        self.torch.cuda.synchronize()
+        for w in self._transfer(self._sides()):
+            w.wait()
+        return 0
 
     # -- setup ----------------------------------------------------------------------------
     def set_materials(self, eps=None, mu=None, allow_uniform=True):
@@ -293,6 +318,10 @@ class SlabRunner:
         # grids below 2*(2*cycle+6) rows have no temporally blocked pass (the engine advances
         # them with its single-step kernels), hence nothing to issue in pieces
         can_overlap = self.overlap and self.rows >= 2 * (2 * cycle + 6)
+        if self.loop == "c":
+            self.engine.run_slab(nsteps, cycle, can_overlap, src_row, src_col, amps)
+            self.steps_done += nsteps
+            return self
         with self._on_stream():
             while done < nsteps:
                 n = nsteps - done if self.world == 1 else min(cycle, nsteps - done)
@@ -321,6 +350,8 @@ class SlabRunner:
             return self
         cycle = self.cycle or 0
         tail = nsteps % cycle if cycle else nsteps
+        if self.loop == "c":           # (the C loop refreshes the halos itself; warm the tail kernels only)
+            return self
         with self._on_stream():
             if self.world > 1 and not self._halo_fresh:
                 self.exchange()

@@ -255,6 +255,33 @@ int fdtd2d_halo_pack(fdtd2d_t *h, int side, void *dev_buf);
  * current.  Both sides that have a neighbour must be unpacked to restore validity. */
 int fdtd2d_halo_unpack(fdtd2d_t *h, int side, const void *dev_buf);
 
+/* ---- the row-slab run loop in C ("distributed communication backend") --------
+ * fdtd2d_run_slab() enqueues a rank's WHOLE run -- per cycle of `cycle` steps: the rows next to the
+ * cuts first (on an internal edge stream), pack, neighbour exchange, meanwhile the interior on the
+ * handle's stream, commit, unpack -- so that no host-language code runs per exchange cycle.  It
+ * replaces the per-cycle calls above for callers that attach a transport:
+ *   fdtd2d_slab_attach_rccl   built-in: RCCL point-to-point (ncclSend / ncclRecv, one group per cycle on
+ *                             the edge stream) with ranks rank-1 / rank+1 of a communicator created
+ *                             from `unique_id128` (fdtd2d_rccl_unique_id() on rank 0, distributed by the
+ *                             caller, e.g. torch.distributed.broadcast); the library loads librccl.so
+ *                             with dlopen and owns the message buffers;
+ *   fdtd2d_slab_attach        the caller's transport function and device message buffers
+ *                             (fdtd2d_halo_bytes() each; NULL for a side without neighbour).
+ * fn(ctx, send_top, recv_top, send_bottom, recv_bottom, bytes, stream) must ENQUEUE on `stream` (a
+ * hipStream_t) -- or complete before returning -- the transfer of this rank's packed send buffers to
+ * the neighbours' recv buffers (NULL pointers: no neighbour on that side); return 0 on success.
+ * Every rank must pass the same nsteps, cycle (<= halo; what all ranks' fdtd2d_info(CYCLE_STEPS)
+ * agree on) and overlap flag: ranks that disagree post their transfers in different orders. */
+typedef int (*fdtd2d_exchange_fn)(void *ctx, void *send_top, void *recv_top, void *send_bottom,
+                                  void *recv_bottom, long long bytes, void *stream);
+int fdtd2d_slab_attach(fdtd2d_t *h, void *send_top, void *recv_top, void *send_bottom, void *recv_bottom,
+                       fdtd2d_exchange_fn fn, void *ctx);
+int fdtd2d_rccl_unique_id(void *out128);
+int fdtd2d_slab_attach_rccl(fdtd2d_t *h, const void *unique_id128, int rank, int world);
+int fdtd2d_slab_detach(fdtd2d_t *h);
+int fdtd2d_run_slab(fdtd2d_t *h, int nsteps, int cycle, int overlap, int src_row, int src_col,
+                    const double *amps);
+
 /* ---- consumers of Ez next to the loop ---------------------- */
 
 /* Device-side first half of capture_snapshot (main.py:153-179): clip Ez to [vmin,vmax], map

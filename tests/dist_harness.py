@@ -36,7 +36,7 @@ def worker(rank, world, port, job, outdir):
         dtype = np.dtype(job["dtype"])
         runner = SlabRunner(rows, cols, job["dt"], job["dx"], dtype=dtype, device=0,
                             engine_factory=factory, overlap=job.get("overlap", True),
-                            boundary=job.get("boundary", "mur"))
+                            boundary=job.get("boundary", "mur"), loop=job.get("loop", "auto"))
         lo, hi = runner.engine.stored_rows
         r0, r1 = runner.engine.owned_rows
         st = np.load(job["state"])

@@ -17,7 +17,7 @@ depend on the local libm/NumPy exp), and the reference outputs for
   * float32 arrays  -- the same reference code handed arrays cast to float32
     (the like-for-like comparison for the fp32 device path).
 
-Usage:  python tests/golden/make_golden.py          (from the repo root)
+Usage:  python tests/golden/make_golden.py [g7]     (from the repo root; `g7` writes only that case)
 """
 import os
 import sys
@@ -108,9 +108,22 @@ def loop_case(ref, name, rows, cols, eps, src, nsteps, snaps, keep_f32_snaps=Tru
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
 
 
+def g7_case(ref):
+    # G7: 2000 steps (the length SURVEY.md M3 states its fp32-vs-fp64 tolerance for): 96x96 vacuum,
+    # the pulse crosses the Mur frame several times; final fields only
+    r, c = 96, 96
+    e, m = ref.material_init(None, r, c)
+    loop_case(ref, "g7_vacuum_96x96_2000", r, c, e, (48, 40), 2000, {2000}, keep_f32_snaps=False)
+
+
 def main():
     ref = load_reference()
     eps0 = 8.85418e-12
+    if len(sys.argv) > 1 and sys.argv[1] == "g7":      # add the newest case without rewriting the others
+        g7_case(ref)
+        print("g7 written")
+        return
+    g7_case(ref)
 
     # G1, G6: isolated half-steps (non-square, varying eps; minimum sizes)
     single_call_case(ref, "g1_single_48x40", 48, 40, 1234)

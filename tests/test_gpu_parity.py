@@ -104,7 +104,7 @@ def test_config1_fp32_device_vs_fp64_reference(fd, onp, golden_dir):
     assert np.array_equal(Ez, g["Ez_f32_500"])
 
 
-def test_fp32_device_vs_fp64_reference_2000_steps(fd, onp, golden_dir):
+def test_fp32_device_vs_fp64_reference_1200_steps(fd, onp, golden_dir):
     """64x64 vacuum, 1200 steps with boundary reflections: e <= 1e-4."""
     g = np.load(os.path.join(golden_dir, "g2_vacuum_64x64.npz"))
     with fd.Engine(64, 64, DT, DX, dtype=np.float32) as eng:
@@ -112,6 +112,24 @@ def test_fp32_device_vs_fp64_reference_2000_steps(fd, onp, golden_dir):
         eng.run(1200, 32, 32, g["amps"])
         for a, k in zip(eng.download(), ("Ez", "Hx", "Hy")):
             assert _rel(a, g[f"{k}_f64_1200"]) <= 1e-4, k
+
+
+@pytest.mark.parametrize("tag,dtype", DTYPES)
+def test_2000_steps_against_the_reference(fd, onp, golden_dir, tag, dtype):
+    """SURVEY.md M3 at its full length: 96x96 vacuum, 2000 steps of the reference (the pulse crosses
+    the Mur frame several times).  The device result in type T equals the reference run on arrays of
+    type T value for value; the float32 device result is within e = max|x - ref| / max|ref| <= 1e-4
+    of the float64 reference (the tolerance BASELINE.md states for up to 2000 steps)."""
+    g = np.load(os.path.join(golden_dir, "g7_vacuum_96x96_2000.npz"))
+    sr, sc = (int(v) for v in g["src"])
+    with fd.Engine(96, 96, DT, DX, dtype=dtype) as eng:
+        eng.set_materials()
+        eng.run(2000, sr, sc, g["amps"])
+        got = eng.download()
+    for a, k in zip(got, ("Ez", "Hx", "Hy")):
+        assert np.array_equal(a, g[f"{k}_{tag}_2000"]), k
+        if dtype == np.float32:
+            assert _rel(a, g[f"{k}_f64_2000"]) <= 1e-4, (k, _rel(a, g[f"{k}_f64_2000"]))
 
 
 # ---- against the oracle on seeded random inputs ------------------------------------------------
@@ -259,6 +277,99 @@ def test_full_size_config2_properties(fd, onp, corc):
                           ref[0][m // 2 - 100:m // 2 + 100, m // 2 - 100:m // 2 + 100])
     assert np.array_equal(Hx[c0 - 100:c0 + 100, c0 - 100:c0 + 100],
                           ref[1][m // 2 - 100:m // 2 + 100, m // 2 - 100:m // 2 + 100])
+
+
+def _ring_eps(onp, rows, cols, r0=0, r1=None):
+    """BASELINE configs[2] geometry: bus waveguide + ring, core eps_r = 10."""
+    r1 = rows if r1 is None else r1
+    i = np.arange(r0, r1, dtype=np.float64)[:, None]
+    j = np.arange(cols, dtype=np.float64)[None, :]
+    core = (i >= np.floor(0.18 * rows)) & (i < np.floor(0.22 * rows))
+    core = core | (np.abs(np.sqrt((i - 0.54 * rows) ** 2 + (j - 0.50 * cols) ** 2) - 0.30 * rows) <= 0.02 * rows)
+    return np.where(core, 10.0 * onp.EPS0, onp.EPS0).astype(np.float32)
+
+
+def _passes_vs_steps(fd, onp, rows, cols, eps, steps, src, amps, seed):
+    """The same run from the same random state with temporally blocked passes and with the
+    single-step kernels (verified against the oracle cell for cell at small sizes): every band,
+    strip and zone seam of the full-size launch must leave no trace.  Returns the pass result."""
+    rng = np.random.default_rng(seed)
+    init = [rng.standard_normal((rows, cols), dtype=np.float32),
+            rng.standard_normal((rows, cols - 1), dtype=np.float32) * np.float32(1e-3),
+            rng.standard_normal((rows - 1, cols), dtype=np.float32) * np.float32(1e-3)]
+    outs = []
+    for max_steps in (None, 0):
+        with fd.Engine(rows, cols, DT, DX, dtype=np.float32) as eng:
+            if eps is None:
+                eng.set_materials()
+            else:
+                eng.set_materials(eps, np.float32(onp.MU0))
+            if max_steps is not None:
+                eng.set_option(max_pass_steps=max_steps)
+            eng.upload(*init)
+            eng.run(steps, src[0], src[1], amps)
+            assert (eng.info(16) > 0) == (max_steps is None)      # passes really ran / really did not
+            outs.append(eng.download())
+    for a, b, k in zip(outs[0], outs[1], ("Ez", "Hx", "Hy")):
+        assert np.array_equal(a, b), f"{k}: passes and single steps differ at {np.argwhere(a != b)[:3]}"
+    return outs[0]
+
+
+def test_full_size_16384_uniform(fd, onp, corc):
+    """The grid BASELINE's 1-GPU target is quoted on, 16384x16384 fp32 uniform, Mur frame.
+    (i) 52 steps (16-step passes + a short tail) from a random state equal the single-step kernels on
+    every cell; (ii) from zero fields, 300 steps of the ricker source: causality (cells further than
+    the steps from the source are exactly zero), the transpose relation of a centred source, and
+    the window around the source equal to a 512x512 run of the C oracle."""
+    n = 16384
+    rng = np.random.default_rng(5)
+    _passes_vs_steps(fd, onp, n, n, None, 52, (n // 2 + 3, 5000), rng.standard_normal(52), 16384)
+    steps = 300
+    amps = np.array([onp.ricker_amplitude(i * DT, FC) for i in range(400, 400 + steps)])
+    with fd.Engine(n, n, DT, DX, dtype=np.float32) as eng:
+        eng.set_materials()
+        eng.run(steps, n // 2, n // 2, amps)
+        Ez, Hx, Hy = eng.download()
+    c0, reach = n // 2, steps + 2
+    assert np.abs(Ez).max() > 0.05
+    assert not Ez[:c0 - reach].any() and not Ez[c0 + reach:].any()
+    assert not Ez[:, :c0 - reach].any() and not Ez[:, c0 + reach:].any()
+    w = slice(c0 - 60, c0 + 60)
+    assert np.array_equal(Ez[w, w], Ez[w, w].T) and np.array_equal(Hx[w, w], -Hy[w, w].T)
+    m = 512
+    ref = onp.grid_zeros(m, m, np.float32)
+    e, mu = onp.vacuum_materials(m, m, np.float32)
+    corc.run(*ref, e, mu, DT, DX, steps, m // 2, m // 2, amps=amps)
+    for a, b in ((Ez, ref[0]), (Hx, ref[1]), (Hy, ref[2])):
+        assert np.array_equal(a[c0 - 100:c0 + 100, c0 - 100:c0 + 100], b[m // 2 - 100:m // 2 + 100, m // 2 - 100:m // 2 + 100])
+
+
+def test_full_size_config3_ring(fd, onp, corc):
+    """BASELINE configs[2]: 8192x8192 fp32, ring-resonator eps map (array eps, uniform mu).
+    (i) 40 steps from a random state: passes equal single steps on every cell; (ii) 200 steps of the
+    source inside the bus waveguide: the 160x160 window around it equals the C oracle run on the
+    640x640 sub-grid with the same local eps (its boundary is outside the window's domain of
+    dependence), and cells beyond the reach of the source are exactly zero."""
+    n = 8192
+    eps = _ring_eps(onp, n, n)
+    rng = np.random.default_rng(6)
+    _passes_vs_steps(fd, onp, n, n, eps, 40, (int(0.20 * n), int(0.20 * n)), rng.standard_normal(40), 8192)
+    steps, sr, sc = 200, int(0.20 * n), int(0.20 * n)
+    amps = np.array([onp.ricker_amplitude(i * DT, FC) for i in range(400, 400 + steps)])
+    with fd.Engine(n, n, DT, DX, dtype=np.float32) as eng:
+        eng.set_materials(eps, np.float32(onp.MU0))
+        assert eng.info(9) == 0
+        eng.run(steps, sr, sc, amps)
+        Ez, Hx, Hy = eng.download()
+    assert np.abs(Ez).max() > 1e-3
+    reach = steps + 2
+    assert not Ez[sr + reach:].any() and not Ez[:, sc + reach:].any()
+    h = 320                                            # half width of the oracle's sub-grid
+    sub = np.ascontiguousarray(eps[sr - h:sr + h, sc - h:sc + h])
+    ref = onp.grid_zeros(2 * h, 2 * h, np.float32)
+    corc.run(*ref, sub, np.full((2 * h, 2 * h), onp.MU0, np.float32), DT, DX, steps, h, h, amps=amps)
+    for a, b in ((Ez, ref[0]), (Hx, ref[1]), (Hy, ref[2])):
+        assert np.array_equal(a[sr - 80:sr + 80, sc - 80:sc + 80], b[h - 80:h + 80, h - 80:h + 80])
 
 
 # ---- error behaviour -----------------------------------------------------------------------------

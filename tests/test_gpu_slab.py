@@ -16,6 +16,11 @@ DT, DX = 5e-14, 1e-4
 
 @pytest.mark.parametrize("world,shape,dtype,materials,overlap,options", [
     (2, (200, 300), "float32", "array", True, None),
+    (2, (200, 300), "float32", "array", True, {"loop": "c"}),               # the run loop in C (fdtd2d_run_slab)
+    (3, (300, 1100), "float32", "uniform", True, {"max_pass_steps": 16, "loop": "c"}),
+    (3, (180, 520), "float32", "array", False, {"loop": "c"}),
+    (4, (160, 520), "float32", "uniform", True, {"max_pass_steps": 16}),    # BASELINE configs[3]: 4 slabs
+    (4, (160, 520), "float32", "array", True, {"max_pass_steps": 16, "loop": "c"}),
     (3, (180, 520), "float32", "array", True, None),
     (2, (128, 256), "float64", "array", True, None),
     (2, (160, 700), "float32", "uniform", True, None),
@@ -33,6 +38,8 @@ def test_gpu_slabs_match_single_engine_and_oracle(tmp_path, world, shape, dtype,
     import fdtd2d_amd as fd
     from oracle import fdtd_numpy as onp
     r, c = shape
+    options = dict(options or {})
+    loop = options.pop("loop", "python")
     n = 45 if options else 29                # exchange cycles 8+8+8+5 (passes 8,8,8,4,1) / 16+16+13
     rng = np.random.default_rng(r + c)
     st = dict(Ez=rng.standard_normal((r, c)), Hx=rng.standard_normal((r, c - 1)) * 1e-3,
@@ -46,7 +53,7 @@ def test_gpu_slabs_match_single_engine_and_oracle(tmp_path, world, shape, dtype,
     extent = (options or {}).get("extent") or (1, 1)
     src = (r // world, c // 2 - extent[1] // 2)       # on the first cut
     job = dict(engine="hip", shape=shape, dtype=dtype, dt=DT, dx=DX, state=path, src=src,
-               chunks=[n], materials=materials, overlap=overlap,
+               chunks=[n], materials=materials, overlap=overlap, loop=loop,
                options={k: v for k, v in (options or {}).items() if k != "extent"} or None,
                extent=(options or {}).get("extent"))
     got = run_job(world, job, str(tmp_path))
@@ -90,12 +97,15 @@ def test_gpu_slabs_probe_next_to_the_cut(tmp_path, probe_row):
     assert np.array_equal(got, np.array(want))
 
 
-def test_gpu_slabs_pml_match_single_engine(tmp_path):
-    """boundary="pml" over 2 slabs (4-field halo messages, single-step kernels consuming the
-    halo) equals the single-engine PML run bit for bit."""
+@pytest.mark.parametrize("options,n,loop", [(None, 21, "python"), ({"max_pass_steps": 16}, 45, "python"),
+                                            ({"max_pass_steps": 16}, 45, "c")])
+def test_gpu_slabs_pml_match_single_engine(tmp_path, options, n, loop):
+    """boundary="pml" over 2 slabs (4-field halo messages) equals the single-engine PML run bit for
+    bit: 8-step passes + single steps consuming the halo, and overlapped 16-step cycles on the
+    level-split PML pair (edge rows first, 4-field pack, interior behind the transfer)."""
     import fdtd2d_amd as fd
     from oracle import fdtd_numpy as onp
-    r, c, n = 220, 260, 21
+    r, c = 220, 260
     rng = np.random.default_rng(5)
     st = dict(Ez=np.zeros((r, c)), Hx=np.zeros((r, c - 1)), Hy=np.zeros((r - 1, c)),
               eps=onp.EPS0 * rng.uniform(1, 3, (r, c)), mu=onp.MU0 * np.ones((r, c)),
@@ -104,11 +114,13 @@ def test_gpu_slabs_pml_match_single_engine(tmp_path):
     path = os.path.join(str(tmp_path), "state.npz")
     np.savez(path, **st)
     job = dict(engine="hip", shape=(r, c), dtype="float32", dt=DT, dx=DX, state=path, src=(110, 130),
-               chunks=[n], materials="array", boundary="pml")
+               chunks=[n], materials="array", boundary="pml", options=options, loop=loop)
     got = run_job(2, job, str(tmp_path))
     with fd.Engine(r, c, DT, DX, dtype=np.float32, boundary="pml") as eng:
         eng.set_materials(st["eps"].astype(np.float32), st["mu"].astype(np.float32))
         eng.set_pml()
+        if options:
+            eng.set_option(**options)
         eng.run(n, 110, 130, st["amps"])
         one = eng.download()
     assert np.abs(one[0]).max() > 0

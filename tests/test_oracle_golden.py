@@ -53,7 +53,8 @@ def _materials(g, dtype):
 
 @pytest.mark.parametrize("impl_name", ["numpy", "c"])
 @pytest.mark.parametrize("tag,dtype", DTYPES)
-@pytest.mark.parametrize("name", ["g2_vacuum_64x64", "g3_disk_64x80", "g4_config1_256x256"])
+@pytest.mark.parametrize("name", ["g2_vacuum_64x64", "g3_disk_64x80", "g4_config1_256x256",
+                                  "g7_vacuum_96x96_2000"])
 def test_time_loop(golden_dir, name, tag, dtype, impl_name):
     g = _load(golden_dir, name)
     r, c, n = int(g["rows"]), int(g["cols"]), int(g["nsteps"])

@@ -42,6 +42,49 @@ def test_split_field_layer_absorbs_better_than_mur_cpu():
     assert res_p * 10 < res_m, (res_p, res_m)
 
 
+def test_layer_reflection_normal_and_oblique_incidence():
+    """Physics pin for the build-defined layer (nothing in the reference can pin it): the reflection a
+    probe next to the layer sees, R = max_t |E - E_open| / max_t |E_open| with E_open from the same
+    source on a grid so large that nothing comes back in time.  A graded split-field layer with
+    R0 = 1e-6 is designed for exp(-2 (m+1)^-1 ... ) = R0^cos(theta) in the continuum; on the grid
+    (20 cells per wavelength, Courant 0.48) the discretisation error of the 40-cell cubic profile
+    dominates, and the classic result is a reflection of order 1e-4..1e-3 that grows towards grazing
+    incidence.  Asserted: R <= 2e-3 at normal incidence, <= 1e-2 at ~45 degrees, both at least 10x below
+    what the reference's first-order Mur frame reflects at the same probes."""
+    from oracle import fdtd_numpy as onp
+    from oracle import pml_numpy as pm
+    dt, dx, fc, n = 1.6e-13, 1e-4, 1.5e11, 420
+    S = (1 / np.sqrt(onp.EPS0 * onp.MU0) * dt) / dx
+    amps = [onp.ricker_amplitude(i * dt, fc) for i in range(n)]
+    small, big, L = 200, 520, 40
+    off = (big - small) // 2
+    probes = {"normal": (100, 150), "oblique": (148, 150)}      # layer starts at column / row 160
+
+    def run(size, boundary):
+        eps, mu = onp.vacuum_materials(size, size)
+        Ez, Hx, Hy = onp.grid_zeros(size, size)
+        Ezx = np.zeros_like(Ez)
+        P = pm.profiles(size, size, S, L=L)
+        o = 0 if size == small else off
+        series = {k: [] for k in probes}
+        for i in range(n):
+            if boundary == "pml":
+                pm.leapfrog(Ez, Ezx, Hx, Hy, eps, mu, dt, dx, 1, 100 + o, 100 + o, [amps[i]], P)
+            else:
+                onp.leapfrog(Ez, Hx, Hy, eps, mu, dt, dx, 1, 100 + o, 100 + o, amps=[amps[i]])
+            for k, (r, c) in probes.items():
+                series[k].append(Ez[r + o, c + o])
+        return {k: np.array(v) for k, v in series.items()}
+
+    open_ = run(big, "pml")          # 160 cells further out in every direction: nothing returns in 420 steps
+    pml, mur = run(small, "pml"), run(small, "mur")
+    refl = {k: (np.abs(pml[k] - open_[k]).max() / np.abs(open_[k]).max(),
+                np.abs(mur[k] - open_[k]).max() / np.abs(open_[k]).max()) for k in probes}
+    assert np.abs(open_["normal"]).max() > 1e-2
+    assert refl["normal"][0] <= 2e-3 and refl["oblique"][0] <= 1e-2, refl
+    assert refl["normal"][0] * 10 < refl["normal"][1] and refl["oblique"][0] * 10 < refl["oblique"][1], refl
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("shape,L", [((96, 130), 20), ((200, 301), 40)])
@@ -91,7 +134,9 @@ def test_device_pml_run_fdtd_absorbs():
 @pytest.mark.parametrize("shape,L,arrays", [((96, 130), 20, True), ((200, 301), 40, False), ((150, 600), 30, True),
                                              ((64, 64), 10, False)])
 def test_device_pml_passes_match_oracle(dtype, shape, L, arrays):
-    """8-step PML passes (k_pass_pml) + remainder steps, source inside the layer's cone."""
+    """PML passes + remainder steps, source inside the layer's cone: 16-step passes on the
+    level-split pair k_bulk_split / k_bulk_split_pml (float32; 27 steps = two short passes of 14 and
+    13 levels), 8-step passes on k_pass_pml (3 passes + 3 single steps), single steps only."""
     import fdtd2d_amd as fd
     from oracle import fdtd_numpy as onp
     from oracle import pml_numpy as pm
@@ -110,16 +155,15 @@ def test_device_pml_passes_match_oracle(dtype, shape, L, arrays):
     ref = [Ez.copy(), np.zeros_like(Ez), Hx.copy(), Hy.copy()]
     pm.leapfrog(*ref, eps, mu, DT, DX, n, sr, sc, amps, P)
     outs = []
-    for max_nt in (8, 0):
+    for max_nt in (16, 8, 0):
         with fd.Engine(r, c, DT, DX, dtype=dtype, boundary="pml") as eng:
             eng.set_materials(eps, mu).set_pml(L=L, courant00=S).set_option(max_pass_steps=max_nt)
             eng.upload(Ez, Hx, Hy)
             eng.run(n, sr, sc, amps)
             got = eng.download()
             gx = eng.download_ezx()
-            assert eng.info(16) == (3 if max_nt else 0)
+            assert eng.info(16) == {16: 2 if dtype == np.float32 else 3, 8: 3, 0: 0}[max_nt]
         outs.append((got[0], gx, got[1], got[2]))
-    for a, b, k in zip(outs[0], ref, ("Ez", "Ezx", "Hx", "Hy")):
-        assert np.array_equal(a, b), f"{k}: passes vs oracle {np.argwhere(a != b)[:4]}"
-    for a, b, k in zip(outs[1], ref, ("Ez", "Ezx", "Hx", "Hy")):
-        assert np.array_equal(a, b), f"{k}: step kernels vs oracle"
+    for out, what in zip(outs, ("16-step passes", "8-step passes", "step kernels")):
+        for a, b, k in zip(out, ref, ("Ez", "Ezx", "Hx", "Hy")):
+            assert np.array_equal(a, b), f"{k}: {what} vs oracle {np.argwhere(a != b)[:4]}"

@@ -914,7 +914,8 @@ static bool plan_pass(const fdtd2d *h, int rem, int *nt, int *nlev, int *lo, int
 static int tune_pass(fdtd2d *h, int nt, int lo, int hi, bool zt, bool zb)
 {
     const std::array<int, 3> key{nt, lo, hi};
-    if (!h->autotune || h->stream_band_rows > 0 || nt < 8 || h->boundary != FDTD2D_BOUNDARY_MUR5 ||
+    if (!h->autotune || h->stream_band_rows > 0 || nt < 8 ||
+        (h->boundary != FDTD2D_BOUNDARY_MUR5 && !h->pml_split(nt)) ||
         (h->long_shape.band_rows > 0 && nt == h->cycle_steps()) ||
         (size_t)std::max(0, hi - lo) * h->cols < ((size_t)4 << 20) || h->tuned.count(key))
         return 0;
@@ -928,6 +929,9 @@ static int tune_pass(fdtd2d *h, int nt, int lo, int hi, bool zt, bool zb)
         for (int br : ladder)
             if (br * 4 <= hi - lo) cand.push_back({br, both_nw ? nw : 0});
     }
+    if (h->pml_split(nt))                       // the PML pair: plain band height x layer band height
+        for (int br : ladder)
+            if (br * 4 <= hi - lo) cand.push_back({br, 0, 128});
     // Shapes that fill the GPU's workgroup slots in k whole rounds, with the first / last strip
     // (~2x the work per row) cut into shorter bands: a launch lasts as long as its longest-lived
     // workgroup, and one that needs 1.1 rounds lasts as long as two.  The zone tiles come first in
@@ -1020,7 +1024,7 @@ int fdtd2d_prepare(fdtd2d_t *h, int nsteps)
     while (left > 0 && rc == 0) {
         int nt = 0, nlev = 0, lo = 0, hi = 0;
         if (!plan_pass(h, left, &nt, &nlev, &lo, &hi)) break;      // single-step kernels: nothing to prepare
-        rc = (nt >= 8 && nlev == nt && h->boundary == FDTD2D_BOUNDARY_MUR5) ? tune_pass(h, nt, lo, hi, h->top(), h->bottom())
+        rc = (nt >= 8 && nlev == nt && (h->boundary == FDTD2D_BOUNDARY_MUR5 || h->pml_split(nt))) ? tune_pass(h, nt, lo, hi, h->top(), h->bottom())
                                                                             : warm(nt, lo, hi, nlev);
         if (nlev == nt && left >= 2 * nt) left %= nt;               // the full passes of a long run are all alike
         else left -= nlev;

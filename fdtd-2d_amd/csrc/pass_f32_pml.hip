@@ -21,7 +21,8 @@ template <bool CE_ARR> static int launch_pml_split(fdtd2d *h, fdtd::PassParams<f
     while (n_right < ns - n_left && x0_of(ns - 1 - n_right) + SW > C - 1 - L) ++n_right;
     const int inner = ns - n_left - n_right;
     // rows whose 16-step cone can touch the top / bottom layer: [0, L + 1 + 2 NT) and the mirror
-    const int reach = L + 1 + 2 * NT, re = std::max(16, h->pml_layer_rows);
+    const int reach = L + 1 + 2 * NT;
+    const int re = std::max(16, h->shape_now.edge_rows > 0 ? h->shape_now.edge_rows : h->pml_layer_rows);
     auto up = [&](int x) { return (x + re - 1) / re * re; };
     int a_hi = p.band_lo, c_lo = p.band_hi;
     if (inner > 0) {

@@ -220,8 +220,9 @@ template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, 
     }
     p.band_rows = std::max(br, 1);
     p.band_rows_e = h->shape_now.edge_rows > 0 ? h->shape_now.edge_rows : p.band_rows;
-    h->shape_last = fdtd2d::Shape{p.band_rows, h->use_level_split(nt, band_lo, band_hi) ? h->split_waves_for(nt, band_lo, band_hi) : 1,
-                                  p.band_rows_e};
+    h->shape_last = fdtd2d::Shape{p.band_rows,
+                                  h->pml_split(nt) ? 4 : (h->use_level_split(nt, band_lo, band_hi) ? h->split_waves_for(nt, band_lo, band_hi) : 1),
+                                  h->pml_split(nt) ? (h->shape_now.edge_rows > 0 ? h->shape_now.edge_rows : h->pml_layer_rows) : p.band_rows_e};
     p.zone_top = ztop;
     p.zone_bot = zbot;
     p.trash = (T *)h->trash;

@@ -159,7 +159,7 @@ def time_single(fd, rows, cols, steps, warmup, materials, device, boundary="mur"
     import torch
     eng = make_engine(fd, rows, cols, materials, device, boundary, shape, autotune)
     sr, sc = rows // 2, cols // 2
-    eng.prepare(steps)          # launch-shape tuner (trial launches, state untouched): part of set-up
+    eng.prepare(steps, sr, sc)  # launch-shape tuner (trial launches, state untouched): part of set-up
     eng.run(warmup, sr, sc, amplitudes(fd, 0, warmup)).sync()
     amps = amplitudes(fd, warmup, steps)
     l0 = eng.info(16), eng.info(17)
@@ -198,7 +198,7 @@ def pmc_child(args):
     eng = make_engine(fd, args.grid, args.cols, args.materials, 0, args.boundary, shape)
     cyc = eng.cycle_steps
     n = cyc * 12
-    eng.prepare(n)
+    eng.prepare(n, args.grid // 2, args.cols // 2)
     eng.run(n, args.grid // 2, args.cols // 2, amplitudes(fd, 0, n)).sync()
     print(json.dumps({"pmc_child": True, "shape": list(eng.last_shape), "cycle": cyc}), flush=True)
     eng.close()

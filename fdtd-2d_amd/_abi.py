@@ -50,6 +50,7 @@ SIGNATURES = {
     "fdtd2d_add_point": (_i, [_vp, _i, _i, _d]),
     "fdtd2d_set_source_extent": (_i, [_vp, _i, _i]),
     "fdtd2d_prepare": (_i, [_vp, _i]),
+    "fdtd2d_prepare_run": (_i, [_vp, _i, _i, _i, _i]),
     "fdtd2d_set_probe": (_i, [_vp, _i, _i, C.c_longlong]),
     "fdtd2d_read_probe": (_i, [_vp, _vp, C.c_longlong, C.c_longlong]),
     "fdtd2d_run": (_i, [_vp, _i, _i, _i, C.POINTER(_d)]),

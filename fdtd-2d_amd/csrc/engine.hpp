@@ -94,16 +94,17 @@ struct fdtd2d {
     int level_split = -1;        // k_bulk_split for 8-step passes: -1 / 1 = yes (measured faster than
                                  // k_bulk at every size, float32 and float64:
                                  // profiles/r01_split8_vs_bulk.txt), 0 = k_bulk
-    // 24-step passes (4 waves x 6 levels, zones as k_zone beside the bulk): float32 + Mur frame only,
+    // 20-step passes (4 waves x 5 levels with one row of HBM prefetch: the same 8 register slots and
+    // 4 waves per SIMD as the 16-step form; zones as k_zone beside the bulk): float32 + Mur frame only,
     // whole grids (a slab's 16-row halo does not feed them), no probe tile.  One such pass takes
-    // 17..24 remaining steps in ONE sweep; it pays only where the sweep dominates -- us per run(20) as
-    // one 24-step-kernel pass vs a 16- and a 4-step pass: 16384^2 2544 vs 2913, 8192^2 850 vs 860,
-    // 4096^2 329 vs 240 (profiles/r02_long_passes.txt) -- hence the size rule (FDTD2D_OPT_MAX_PASS_STEPS
-    // = 24 lifts it, as 16 does for the 16-step rule).
+    // 17..20 remaining steps in ONE sweep; it pays where the sweep dominates -- us per run(20) as one
+    // 20-step pass vs a 16- and a 4-step pass: 16384^2 1827 vs 2914, 8192^2 870 vs 942, 4096^2 317 vs
+    // 250 (profiles/r02_long_passes.txt) -- hence the size rule (FDTD2D_OPT_MAX_PASS_STEPS = 20 lifts
+    // it, as 16 does for the 16-step rule).
     bool long_passes() const
     {
-        if (dtype != FDTD2D_F32 || boundary != FDTD2D_BOUNDARY_MUR5 || max_nt < 24 || probe_cap) return false;
-        return max_nt_forced || (size_t)nrows * cols >= (size_t)128 << 20;
+        if (dtype != FDTD2D_F32 || boundary != FDTD2D_BOUNDARY_MUR5 || max_nt < 20 || probe_cap) return false;
+        return max_nt_forced || (size_t)nrows * cols >= (size_t)64 << 20;
     }
     // 16-step PML passes: the level-split pair k_bulk_split / k_bulk_split_pml (float32, uniform mu)
     bool pml_split(int nt) const
@@ -113,8 +114,8 @@ struct fdtd2d {
     bool use_level_split(int nt, int band_lo, int band_hi) const
     {
         (void)band_lo, (void)band_hi;
-        if ((nt != 8 && nt != 16 && nt != 24) || boundary != FDTD2D_BOUNDARY_MUR5) return false;
-        if (nt >= 16) return dtype == FDTD2D_F32;      // 16..24-step passes exist in this form only
+        if ((nt != 8 && nt != 16 && nt != 20) || boundary != FDTD2D_BOUNDARY_MUR5) return false;
+        if (nt >= 16) return dtype == FDTD2D_F32;      // 16- and 20-step passes exist in this form only
         // array materials: only the build with fused zone tiles exists
         if ((!ce_uniform || !ch_uniform) && zone_split == 1) return false;
         return level_split != 0;
@@ -136,7 +137,7 @@ struct fdtd2d {
     int split_waves = 0;         // waves per strip in k_bulk_split: 0 = automatic, 4 or 8
     int split_waves_for(int nt, int lo, int hi) const
     {
-        if (nt > 16) return 4;                   // 24 steps: 4 waves x 6 levels
+        if (nt > 16) return 4;                   // 20 steps: 4 waves x 5 levels
         if (!split_waves && shape_now.waves) return shape_now.waves;
         // 4 waves x NT/4 levels on large slabs (what the tuner keeps picking from 4096^2 up); 8 waves
         // x NT/8 levels shorten the tick chain that bounds small ones: 8-step passes 27.8 vs 33.7 us
@@ -159,7 +160,7 @@ struct fdtd2d {
         return std::min(max_nt, 8);
     }
     int zone_split = -1;         // -1: by launch size; 0/1: force fused / side-stream zones (FDTD2D_OPT_ZONE_SPLIT)
-    int max_nt = 24;             // longest pass; FDTD2D_OPT_MAX_PASS_STEPS (0: step kernels only)
+    int max_nt = 20;             // longest pass; FDTD2D_OPT_MAX_PASS_STEPS (0: step kernels only)
 };
 
 

@@ -876,7 +876,7 @@ int fdtd2d_add_point(fdtd2d_t *h, int row, int col, double amp)
 // overlap, zone depth) and the levels *nlev <= *nt it advances.  Every pass is one sweep over the
 // grid whatever its length, so the plan minimises sweeps and never leaves a scrap: a remainder of
 // at most one pass runs on the shortest kernel that holds it (level-split kernels stop after nlev
-// levels; on very large grids a 24-step kernel takes 17..24 steps in one sweep), a remainder
+// levels; on very large grids a 20-step kernel takes 17..20 steps in one sweep), a remainder
 // between one and two passes is cut in halves, longer runs take full passes.  Returns false when
 // no temporally blocked pass is possible from the current state (small grids, an exhausted halo):
 // the caller then takes one plain step.
@@ -886,12 +886,12 @@ static bool plan_pass(const fdtd2d *h, int rem, int *nt, int *nlev, int *lo, int
     if (C <= 0 || rem <= 0) return false;
     const bool longp = C == 16 && h->long_passes();
     int take = rem;
-    if (!(longp && rem <= 24)) {
+    if (!(longp && rem <= 20)) {
         if (rem > 2 * C) take = C;
         else if (rem > C) take = (rem + 1) / 2;
     }
-    const int lens[] = {1, 2, 4, 8, 16, 24};
-    auto avail = [&](int c) { return c <= C || (longp && c == 24); };
+    const int lens[] = {1, 2, 4, 8, 16, 20};
+    auto avail = [&](int c) { return c <= C || (longp && c == 20); };
     for (int c : lens)                      // shortest kernel that holds `take`
         if (c >= take && avail(c) && pass_geometry(h, c, lo, hi) &&
             (c == take || h->use_level_split(c, *lo, *hi) || h->pml_split(c))) {
@@ -911,8 +911,15 @@ static bool plan_pass(const fdtd2d *h, int rem, int *nt, int *nlev, int *lo, int
 // the next committed pass overwrites anyway (commit = false), so the state is untouched.
 // Candidates: the rule of launch_pass, a ladder of band heights, and for 16-step passes both
 // 4 and 8 waves per strip.  Costs about 40 launches the first time a (length, rows) pair is run.
-static int tune_pass(fdtd2d *h, int nt, int lo, int hi, bool zt, bool zb)
+static int tune_pass(fdtd2d *h, int nt, int lo, int hi, bool zt, bool zb, int src_row = 0, int src_col = 0,
+                     bool has_src = false)
 {
+    // (a source changes the launch: its strips run the slower body in short bands of their own, which
+    // can push a launch that just filled the GPU's workgroup slots into a second round -- 4096^2:
+    // 147 -> 170 us per pass, profiles/r02_source_cost.txt -- so the trials carry the source, with
+    // amplitude 0, when the run will)
+    static const double zero_amps[fdtd::STREAM_MAX_NT] = {};
+    const double *trial_amps = has_src ? zero_amps : nullptr;
     const std::array<int, 3> key{nt, lo, hi};
     if (!h->autotune || h->stream_band_rows > 0 || nt < 8 ||
         (h->boundary != FDTD2D_BOUNDARY_MUR5 && !h->pml_split(nt)) ||
@@ -944,10 +951,16 @@ static int tune_pass(fdtd2d *h, int nt, int lo, int hi, bool zt, bool zb)
         const int ns = (h->cols + ow - 1) / ow;
         const int zw = nt == 16 ? 30 : (nt == 8 ? 14 : 0);   // ZoneDims<NT>::WZ (24 steps: zones run beside the bulk)
         const int zones = zw ? ((zt ? 1 : 0) + (zb ? 1 : 0)) * ((h->cols + zw - 1) / zw) : 0;
+        int n_src = 0;                           // inner strips that hold source columns (bands of their own)
+        for (int st = 1; has_src && st <= ns - 2; ++st) {
+            const int x0 = st * ow - fdtd::stream_hc(nt);
+            if (src_col + h->src_cols > x0 && src_col < x0 + 64 * V) ++n_src;
+        }
+        if (n_src > 2) n_src = 0;
         for (int nw : {4, 8}) {
             if (nw == 8 && !both_nw) continue;
-            // resident workgroups (VGPR / LDS limits): 4 (3 at 24 steps) x 4 waves or 2 x 8 per CU
-            const int slots = 256 * (nw == 8 ? 2 : (nt == 24 ? 3 : 4));
+            // resident workgroups (VGPR / LDS limits): 4 x 4 waves or 2 x 8 per CU
+            const int slots = 256 * (nw == 8 ? 2 : 4);
             const double fill = 2.0 * nt + nw - 1;
             for (int k : {1, 2, 3, 4}) {
                 for (double w_e : {1.0, 2.0, 3.0}) {            // edge bands as tall, 1/2, 1/3 as long-lived
@@ -957,7 +970,9 @@ static int tune_pass(fdtd2d *h, int nt, int lo, int hi, bool zt, bool zb)
                         const double life = (double)region / nb + fill;      // ticks of a plain task
                         const double er = life / w_e - fill;                   // rows of an equally long edge task
                         const int ne = w_e == 1.0 ? nb : (er >= 8 ? (int)std::ceil(region / er) : region / 8);
-                        if ((double)std::max(0, ns - 2) * nb + 2.0 * ne > tasks) break;
+                        const int brs = std::max(16, std::min((region + ne - 1) / ne, (region + nb - 1) / nb / 3));
+                        const int n_s = n_src * ((region + brs - 1) / brs);          // workgroups of the source strips
+                        if ((double)std::max(0, ns - 2 - n_src) * nb + 2.0 * ne + n_s > tasks) break;
                         best = fdtd2d::Shape{(region + nb - 1) / nb, both_nw ? nw : 0,
                                              w_e == 1.0 ? 0 : std::max(8, (region + ne - 1) / ne)};
                     }
@@ -977,8 +992,8 @@ static int tune_pass(fdtd2d *h, int nt, int lo, int hi, bool zt, bool zb)
         int rc = 0;
         for (int n = 0; n < reps && rc == 0; ++n)
             rc = h->dtype == FDTD2D_F32
-                     ? launch_pass<float>(h, nt, lo, hi, 0, 0, nullptr, zt, zb, false, lo, hi)
-                     : launch_pass<double>(h, nt, lo, hi, 0, 0, nullptr, zt, zb, false, lo, hi);
+                     ? launch_pass<float>(h, nt, lo, hi, src_row, src_col, trial_amps, zt, zb, false, lo, hi)
+                     : launch_pass<double>(h, nt, lo, hi, src_row, src_col, trial_amps, zt, zb, false, lo, hi);
         return rc;
     };
     int rc = trial(cand[0], 3);                       // clocks up, code objects loaded
@@ -1007,7 +1022,9 @@ static int tune_pass(fdtd2d *h, int nt, int lo, int hi, bool zt, bool zb)
     return rc;
 }
 
-int fdtd2d_prepare(fdtd2d_t *h, int nsteps)
+int fdtd2d_prepare(fdtd2d_t *h, int nsteps) { return fdtd2d_prepare_run(h, nsteps, 0, 0, 0); }
+
+int fdtd2d_prepare_run(fdtd2d_t *h, int nsteps, int src_row, int src_col, int with_source)
 {
     int rc = need_stable(h);
     if (rc) return rc;
@@ -1024,7 +1041,7 @@ int fdtd2d_prepare(fdtd2d_t *h, int nsteps)
     while (left > 0 && rc == 0) {
         int nt = 0, nlev = 0, lo = 0, hi = 0;
         if (!plan_pass(h, left, &nt, &nlev, &lo, &hi)) break;      // single-step kernels: nothing to prepare
-        rc = (nt >= 8 && nlev == nt && (h->boundary == FDTD2D_BOUNDARY_MUR5 || h->pml_split(nt))) ? tune_pass(h, nt, lo, hi, h->top(), h->bottom())
+        rc = (nt >= 8 && nlev == nt && (h->boundary == FDTD2D_BOUNDARY_MUR5 || h->pml_split(nt))) ? tune_pass(h, nt, lo, hi, h->top(), h->bottom(), src_row, src_col, with_source != 0)
                                                                             : warm(nt, lo, hi, nlev);
         if (nlev == nt && left >= 2 * nt) left %= nt;               // the full passes of a long run are all alike
         else left -= nlev;
@@ -1051,7 +1068,7 @@ int fdtd2d_run(fdtd2d_t *h, int nsteps, int src_row, int src_col, const double *
             const double *a = amps ? amps + n : nullptr;
             // (only full passes are tuned: a one-off tail does not pay for 20-120 ms of trial launches;
             // it uses the shape measured for full passes of its kernel if there is one)
-            if (nlev == nt && (rc = tune_pass(h, nt, lo, hi, h->top(), h->bottom()))) return rc;
+            if (nlev == nt && (rc = tune_pass(h, nt, lo, hi, h->top(), h->bottom(), src_row, src_col, amps != nullptr))) return rc;
             h->probe_pending = h->probe_cap > 0;
             rc = h->dtype == FDTD2D_F32
                      ? launch_pass<float>(h, nt, lo, hi, src_row, src_col, a, h->top(), h->bottom(), true, lo, hi, nlev)
@@ -1099,7 +1116,7 @@ int fdtd2d_pass_rows(fdtd2d_t *h, int nt, int row_lo, int row_hi, int src_row, i
         return fail(h, FDTD2D_E_ARG, "rows cut through the bottom zone [%d,%d)", h->rows - zo, h->rows);
     const bool zt = h->top() && row_lo == 0, zb = h->bottom() && row_hi == h->rows;
     const int b_lo = std::max(row_lo, lo), b_hi = std::min(row_hi, hi);
-    if ((rc = tune_pass(h, nt, b_lo, b_hi, zt, zb))) return rc;
+    if ((rc = tune_pass(h, nt, b_lo, b_hi, zt, zb, src_row, src_col, amps != nullptr))) return rc;
     h->probe_pending = h->probe_cap > 0 && h->pend_nt == 0;      // once per pass: with its first piece
     rc = h->dtype == FDTD2D_F32
              ? launch_pass<float>(h, nt, b_lo, b_hi, src_row, src_col, amps, zt, zb, false, lo, hi)
@@ -1177,7 +1194,7 @@ int fdtd2d_set_option(fdtd2d_t *h, int option, long long value)
     if (!h) return FDTD2D_E_ARG;
     switch (option) {
     case FDTD2D_OPT_MAX_PASS_STEPS:
-        if (value < 0 || value > fdtd::STREAM_MAX_NT) return fail(h, FDTD2D_E_ARG, "pass length must be 0..24");
+        if (value < 0 || value > fdtd::STREAM_MAX_NT) return fail(h, FDTD2D_E_ARG, "pass length must be 0..20");
         h->max_nt = (int)value;
         h->max_nt_forced = true;
         return 0;

@@ -132,7 +132,9 @@ __device__ __forceinline__ void split_body(const PassParams<T> &p, const int str
     constexpr int LV = NT / SPLIT_NW, LAG = LV + 1;
     constexpr int HC = stream_hc(NT);
     constexpr int SW = 64 * V, OW = SW - 2 * HC;
-    constexpr int PF = ROLE == 0 ? STREAM_PF : 0;      // only the first wave hides HBM latency
+    // only the first wave hides HBM latency (the 5-level form keeps one row in flight instead of two:
+    // 8 slots of 12 registers like the 4-level form, 4 waves per SIMD)
+    constexpr int PF = ROLE == 0 ? (LV > 4 ? 1 : STREAM_PF) : 0;
     constexpr int S = LV + 2 + PF;              // ring of row slots, tick loop unrolled S times
     const Geom g = p.g;
     const int lane = threadIdx.x & 63;

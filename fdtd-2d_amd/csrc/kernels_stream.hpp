@@ -38,10 +38,10 @@ constexpr int PASS_THREADS = 256;    // threads per zone tile (4 waves share the
 // branched around.  One 4 KiB slot per workgroup (index mod 1024): a single shared line would
 // be written by every CU at once.
 constexpr int TRASH_SLOTS = 1024, TRASH_SLOT_BYTES = 4096;
-constexpr int STREAM_MAX_NT = 24;   // longest pass: 8 levels in one wave; 16 (4 or 8 waves) and 24 (8 waves x 3) with the level-split kernel
+constexpr int STREAM_MAX_NT = 20;   // longest pass: 8 levels in one wave; 16 (4 or 8 waves) and 20 (4 waves x 5) with the level-split kernel
 // halo columns per strip side: >= NT (validity shrinks one column per level from a strip
 // edge) and a multiple of 4 so that every lane's 16-byte access stays aligned
-constexpr int stream_hc(int nt) { return nt <= 4 ? 4 : (nt <= 8 ? 8 : (nt <= 16 ? 16 : 24)); }
+constexpr int stream_hc(int nt) { return nt <= 4 ? 4 : (nt <= 8 ? 8 : (nt <= 16 ? 16 : 20)); }
 
 template <class T> struct PassParams {
     const T *ez_in, *hx_in, *hy_in;
@@ -56,8 +56,8 @@ template <class T> struct PassParams {
     int strip_first;           // first strip of the "inner" set (1; the PML pass gives its layer strips
                                // to another kernel and sets nbands_e = 0)
     int src_strip, n_src;      // inner strips [src_strip, src_strip + n_src) hold the source columns: their
-                               // workgroups near the source rows run the GENERAL body too, so they get the
-                               // short bands of the edge strips (n_src = 0: no such strips)
+    int band_rows_s, nbands_s; // workgroups near the source rows run the slower GENERAL body too and would end
+                               // the launch alone, so these strips get short bands of their own (n_src = 0: none)
     int zone_top, zone_bot;    // 1 if this launch owns the grid's top / bottom zone
     int zone_tiles;            // column tiles per zone
     int fused_zones;           // 1: the zone tiles are the first workgroups of the k_bulk launch
@@ -137,14 +137,19 @@ __device__ __forceinline__ int strip_x0(const PassParams<T> &p, int strip)
 template <class T>
 __device__ __forceinline__ bool strip_of_block(const PassParams<T> &p, int b, int *strip, int *ra, int *rb)
 {
-    if (b < (2 + p.n_src) * p.nbands_e) {
+    if (b < 2 * p.nbands_e) {
         const int sidx = b / p.nbands_e, band = b - sidx * p.nbands_e;
         if (sidx == 1 && p.nstrips == 1) return false;    // the second edge slot stays empty
-        *strip = sidx == 0 ? 0 : (sidx == 1 ? p.nstrips - 1 : p.src_strip + sidx - 2);
+        *strip = sidx == 0 ? 0 : p.nstrips - 1;
         *ra = p.band_lo + band * p.band_rows_e;
         *rb = min(*ra + p.band_rows_e, p.band_hi);
+    } else if ((b -= 2 * p.nbands_e) < p.n_src * p.nbands_s) {
+        const int sidx = b / p.nbands_s, band = b - sidx * p.nbands_s;
+        *strip = p.src_strip + sidx;
+        *ra = p.band_lo + band * p.band_rows_s;
+        *rb = min(*ra + p.band_rows_s, p.band_hi);
     } else {
-        b -= (2 + p.n_src) * p.nbands_e;
+        b -= p.n_src * p.nbands_s;
         const int sidx = b / p.nbands, band = b - sidx * p.nbands;
         int st = sidx + p.strip_first;
         if (p.n_src > 0 && st >= p.src_strip) st += p.n_src;      // the source strips were dealt with above

@@ -15,7 +15,9 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
     // inner strips that hold source columns (at most two neighbours; wider sources get no special bands)
     p.src_strip = 0;
     p.n_src = 0;
-    if (p.src_col1 > p.src_col && p.band_rows_e < p.band_rows && p.nstrips > 2) {
+    p.band_rows_s = std::max(16, std::min(p.band_rows_e, p.band_rows / 3));
+    p.nbands_s = (region + p.band_rows_s - 1) / p.band_rows_s;
+    if (p.src_col1 > p.src_col && p.band_rows_s < p.band_rows && p.nstrips > 2) {
         constexpr int SWc = 64 * V, OWc = SWc - 2 * fdtd::stream_hc(NT);
         int s0 = -1, s1 = -1;
         for (int st = 1; st <= p.nstrips - 2; ++st) {
@@ -33,7 +35,8 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
     p.zone_tiles = (h->cols + D::WZ - 1) / D::WZ;
     // launch order: zone tiles, 2 edge-strip slots (the second stays empty with one strip),
     // then strips 1 .. nstrips-2
-    const long long bulk = (2LL + p.n_src) * p.nbands_e + (long long)p.nbands * std::max(0, p.nstrips - 2 - p.n_src);
+    const long long bulk = 2LL * p.nbands_e + (long long)p.n_src * p.nbands_s +
+                           (long long)p.nbands * std::max(0, p.nstrips - 2 - p.n_src);
     const long long zones = (long long)(p.zone_top + p.zone_bot) * p.zone_tiles;
     if (bulk + zones == 0) return 0;
     if constexpr (NT >= 8) {
@@ -42,8 +45,8 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
             // launch and two cross-stream event waits per pass -- 38 vs 84 us per 8 steps at
             // 2048^2, 96 vs 99 at 4096^2, equal at 16384^2: profiles/r01_zone_fuse_split.txt) or
             // k_zone on the side stream (zone_split = 1)
-            // (24-step passes: 4 waves x 6 levels at 3 workgroups per CU; a fused 54-row zone tile would
-            // take 56 KB of LDS from every workgroup and leave 2, so their zones always run as k_zone)
+            // (20-step passes: 4 waves x 5 levels at 4 workgroups per CU; a fused 46-row zone tile would
+            // take 48 KB of LDS from every workgroup and leave 3, so their zones always run as k_zone)
             const bool side = zones > 0 && (h->zone_split == 1 || NT > 16);
             p.fused_zones = zones > 0 && !side;
             if (side) {
@@ -63,7 +66,7 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
                 const int nw = h->split_waves_for(NT, p.band_lo, p.band_hi);
                 const dim3 grid((unsigned)blocks), wg(64 * nw);
                 if constexpr (NT > 16) {
-                    // 24 steps: 4 waves x 6 levels, zone tiles on the side stream
+                    // 20 steps: 4 waves x 5 levels, zone tiles on the side stream
                     hipLaunchKernelGGL((fdtd::k_bulk_split<T, NT, 4, false, CE_ARR, CH_ARR, V>), grid, wg, 0, h->stream, p);
                 } else {
                 const bool w8 = nw == 8;
@@ -87,7 +90,7 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
         }
     }
     if constexpr (NT > 8) {
-        return fail(h, FDTD2D_E_ARG, "16- to 24-step passes run on the level-split kernel only");
+        return fail(h, FDTD2D_E_ARG, "16- and 20-step passes run on the level-split kernel only");
     } else {
     // Small launches: zone tiles as k_zone on the side stream (ordered behind what is already
     // on h->stream; everything later on h->stream waits for both).  Large launches: fused.
@@ -153,9 +156,9 @@ template <class T> int launch_probe(fdtd2d *h, int nt, const fdtd::PassParams<T>
     }
 }
 
-#ifdef FDTD_PASS_LONG_EXTERN   // the 16- and 24-step float32 kernels are built in translation units of their own
+#ifdef FDTD_PASS_LONG_EXTERN   // the 16- and 20-step float32 kernels are built in translation units of their own
 extern template int launch_pass_nt<float, 16>(fdtd2d *, fdtd::PassParams<float> &);
-extern template int launch_pass_nt<float, 24>(fdtd2d *, fdtd::PassParams<float> &);
+extern template int launch_pass_nt<float, 20>(fdtd2d *, fdtd::PassParams<float> &);
 #endif
 
 // One pass of nt in {1,2,4,8,16} steps; amps = nt amplitudes or nullptr.
@@ -235,6 +238,7 @@ template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, 
     // over the grid for a tail of 3, 5, 6, 7, 9..15 steps instead of one per power of two)
     p.strip_first = 1;
     p.src_strip = p.n_src = 0;
+    p.band_rows_s = p.nbands_s = 1;
     p.nlev = nlev > 0 ? std::min(nlev, nt) : nt;
     if (p.nlev != nt && !h->use_level_split(nt, band_lo, band_hi) && !h->pml_split(nt))
         return fail(h, FDTD2D_E_ARG, "short passes run on the level-split kernels only");
@@ -285,9 +289,9 @@ template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, 
         rc = 0;
     } else
     switch (nt) {
-    case 24:
-        if constexpr (sizeof(T) == 4) { rc = launch_pass_nt<T, 24>(h, p); break; }
-        return fail(h, FDTD2D_E_ARG, "24-step passes are built for float32 only");
+    case 20:
+        if constexpr (sizeof(T) == 4) { rc = launch_pass_nt<T, 20>(h, p); break; }
+        return fail(h, FDTD2D_E_ARG, "20-step passes are built for float32 only");
     case 16:
         if constexpr (sizeof(T) == 4) { rc = launch_pass_nt<T, 16>(h, p); break; }
         return fail(h, FDTD2D_E_ARG, "16-step passes are built for float32 only");

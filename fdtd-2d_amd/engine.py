@@ -221,10 +221,13 @@ class Engine:
     def add_point(self, row, col, amp):
         self._ck(self._lib.fdtd2d_add_point(self._h, int(row), int(col), float(amp)))
 
-    def prepare(self, nsteps):
-        """Measure the launch shapes run(nsteps) will use now (trial launches that leave the
-        fields untouched) instead of inside its first passes."""
-        self._ck(self._lib.fdtd2d_prepare(self._h, int(nsteps)))
+    def prepare(self, nsteps, src_row=None, src_col=None):
+        """Measure the launch shapes run(nsteps[, src_row, src_col, amps]) will use now (trial
+        launches that leave the fields untouched) instead of inside its first passes."""
+        if src_row is None:
+            self._ck(self._lib.fdtd2d_prepare(self._h, int(nsteps)))
+        else:
+            self._ck(self._lib.fdtd2d_prepare_run(self._h, int(nsteps), int(src_row), int(src_col), 1))
         return self
 
     def set_probe(self, row, col, capacity):

@@ -192,6 +192,10 @@ int fdtd2d_run(fdtd2d_t *h, int nsteps, int src_row, int src_col, const double *
  * instead of inside its first passes.  Blocks for the 20-120 ms of trial launches; the fields
  * and the step counter are untouched. */
 int fdtd2d_prepare(fdtd2d_t *h, int nsteps);
+/* The same for a run with its source: the trial launches carry the source rectangle at (src_row,
+ * src_col) with amplitude 0 when with_source != 0 (the strips that hold the source run a slower
+ * body in bands of their own, which changes the best shape on grids that fill the GPU exactly once). */
+int fdtd2d_prepare_run(fdtd2d_t *h, int nsteps, int src_row, int src_col, int with_source);
 
 /* One temporally blocked pass of nt in {1,2,4,8,16} steps issued in pieces, so that a caller can
  * compute the rows its neighbours wait for first, send them, and overlap the transfer with

@@ -319,13 +319,14 @@ def roofline_block(cells, steps, r, traffic):
     return out
 
 
-def single_record(fd, rows, cols, steps, warmup, materials, boundary, device, traffic, pmc, note=""):
+def single_record(fd, rows, cols, steps, warmup, materials, boundary, device, traffic, pmc, note="", shape=None,
+                  autotune=True):
     """Timing of one whole-grid configuration + its roofline block.  traffic: the live PMC result
     (dict), an error string if the live measurement failed, or None."""
     err = traffic if isinstance(traffic, str) else None
     traffic = None if err else traffic
     r = time_single(fd, rows, cols, steps, warmup, materials, device, boundary,
-                    traffic["shape"] if traffic else None)
+                    traffic["shape"] if traffic else shape, autotune)
     if traffic is None and pmc != "off":
         traffic = profile_traffic(rows, cols, materials, boundary, r["launch_steps"])
     cells = rows * cols
@@ -358,6 +359,9 @@ def main():
     ap.add_argument("--exchange", choices=["overlapped", "plain"], default="overlapped")
     ap.add_argument("--no-secondary", action="store_true", help="N=1: skip the configs[1] / configs[2] records")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-autotune", action="store_true",
+                    help="fixed launch-shape rules (for profiler runs: the tuner's trial launches would be "
+                         "averaged into the per-kernel statistics); combine with --band-rows/--waves/--edge-rows")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--band-rows", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--waves", type=int, default=0, help=argparse.SUPPRESS)
@@ -402,8 +406,10 @@ def main():
         import torch
         import fdtd2d_amd as fd
         torch.cuda.set_device(local)
-        out = [single_record(fd, r_, c_, st, wu, mat, bnd, local, t, args.pmc, note)
-               for (r_, c_, st, wu, mat, bnd, note), t in zip(recs, traffic)]
+        forced = (args.band_rows, args.waves, args.edge_rows) if args.band_rows else None
+        out = [single_record(fd, r_, c_, st, wu, mat, bnd, local, t, args.pmc, note, forced if k == 0 else None,
+                             not args.no_autotune)
+               for k, ((r_, c_, st, wu, mat, bnd, note), t) in enumerate(zip(recs, traffic))]
         head = out[0]
         res = {"metric": "Mcell-steps/s", "value": head["value"], "unit": "Mcell-steps/s",
                "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],

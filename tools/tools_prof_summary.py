@@ -2,14 +2,16 @@
 """Condense one tools_prof.sh output directory into a text summary for profiles/."""
 import collections, csv, glob, json, os, sys
 out = sys.argv[1]
-print("command: python bench.py --no-cpu-baseline " + " ".join(sys.argv[2:]))
+print("command: rocprofv3 --kernel-trace --stats -- python bench.py --pmc off --no-cpu-baseline --no-secondary --no-autotune " + " ".join(sys.argv[2:]))
 for leg in ("stats", "pmc_fetch", "pmc_write"):
     log = os.path.join(out, leg + ".log")
     if os.path.exists(log):
         lines = [l for l in open(log).read().splitlines() if l.startswith("{")]
         if lines:
             d = json.loads(lines[-1])
-            print(f"bench line under {leg}: value={d['value']} Mcell-steps/s, roofline={json.dumps(d['roofline'])}")
+            rl = d["roofline"]
+            print(f"bench line under {leg}: value={d['value']} Mcell-steps/s, avg_launch_ms={rl.get('avg_launch_ms')}, "
+                  f"steady_state_value={rl.get('steady_state_value')}, launch_shape={rl.get('launch_shape')}")
 print()
 print("== rocprofv3 --kernel-trace --stats (kernel_stats.csv) ==")
 for f in glob.glob(os.path.join(out, "stats", "*", "*kernel_stats.csv")):
@@ -27,23 +29,4 @@ for f in glob.glob(os.path.join(out, "stats", "*", "*kernel_trace.csv")):
         w = v[-20:]
         print(f"{k[:90]:90s} n={len(v):4d} last{len(w)}_avg_ns={sum(w)/len(w):12.0f}")
 print()
-print("== PMC (separate passes; KiB per dispatch as reported) ==")
-acc = collections.defaultdict(list)
-for leg in ("pmc_fetch", "pmc_write"):
-    for f in glob.glob(os.path.join(out, leg, "*", "*counter_collection.csv")):
-        for r in csv.DictReader(open(f)):
-            acc[(r["Kernel_Name"][:70], r["Counter_Name"])].append(float(r["Counter_Value"]))
-tot = collections.defaultdict(dict)
-for (k, c), v in sorted(acc.items()):
-    # skip warm-up dispatches of the hot kernel: use the last half
-    vv = v[len(v) // 2:] if len(v) > 4 else v
-    mean = sum(vv) / len(vv)
-    tot[k][c] = mean
-    print(f"{k:70s} {c:11s} n={len(v):4d} mean={mean:14.1f} KiB")
-print()
-print("== HBM traffic per launch, corrected as MI355X_MICROARCH.md prescribes ==")
-print("   (FETCH_SIZE counts 128-B requests as 64 B for 16-B/lane streaming reads: x2; WRITE_SIZE exact)")
-for k, d in tot.items():
-    if "FETCH_SIZE" in d and "WRITE_SIZE" in d and d["WRITE_SIZE"] > 1000:
-        rd, wr = 2 * d["FETCH_SIZE"] * 1024, d["WRITE_SIZE"] * 1024
-        print(f"{k:70s} read={rd/1e6:10.1f} MB write={wr/1e6:10.1f} MB total={(rd+wr)/1e6:10.1f} MB")
+print("(HBM traffic of the same kernel and launch shape: collected by bench.py itself, --pmc live)")

@@ -357,6 +357,9 @@ def main():
                     help="roofline.traffic: measured by this run through rocprofv3 child processes, taken "
                          "from the committed profile, or omitted")
     ap.add_argument("--exchange", choices=["overlapped", "plain"], default="overlapped")
+    ap.add_argument("--loop", choices=["auto", "c", "python"], default="auto",
+                    help="N > 1: the run loop in C with the library's RCCL transport (auto on nccl) or the "
+                         "Python-sequenced cycle over torch.distributed")
     ap.add_argument("--no-secondary", action="store_true", help="N=1: skip the configs[1] / configs[2] records")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-autotune", action="store_true",
@@ -443,7 +446,7 @@ def main():
         # No fallback between exchange modes: a failure is printed by the rank that saw it and ends
         # the job (a retry in the same process could match stale messages of the failed attempt).
         runner = SlabRunner(rows, cols, DT, DX, dtype=np.float32, device=local, boundary=boundary,
-                            overlap=(args.exchange == "overlapped"))
+                            overlap=(args.exchange == "overlapped"), loop=args.loop)
         lo, hi = runner.engine.stored_rows
         eps, mu = make_materials(fd, args.materials, rows, cols, lo, hi)
         runner.set_materials(eps, mu, allow_uniform=(args.materials != "array"))
@@ -468,6 +471,7 @@ def main():
         ok = runner.sanity()
         slab = runner.engine.nrows
         exchange_mode = "overlapped" if runner.overlap and rows >= 2 * (2 * cycle + 6) else "plain"
+        loop_used = runner.loop + (" (library RCCL transport)" if runner.loop == "c" and backend == "nccl" else "")
         runner.close()
     except Exception:
         print(f"[rank {rank}] slab run failed:\n{traceback.format_exc()}", file=sys.stderr, flush=True)
@@ -489,7 +493,7 @@ def main():
                                    f"every field every {cycle} steps over {backend} send/recv",
                        "grid": [rows, cols], "materials": args.materials, "boundary": boundary,
                        "per_gpu_slab": [slab, cols], "fields_finite": bool(ok),
-                       "exchange": exchange_mode, "cycle_steps": cycle,
+                       "exchange": exchange_mode, "cycle_steps": cycle, "loop": loop_used,
                        "host_us_per_cycle": round(host_s * 1e6 / ncyc, 1)},
             "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                          "frac": None, "traffic": None,

@@ -121,6 +121,11 @@ template <class T, bool GENERAL, bool CE_ARR, bool CH_ARR, int V> struct StripMa
 // latency, the ticks run at ~95 % of the VALU issue rate those 4 waves can reach.)
 constexpr int HAND_DEPTH = 2;
 
+// (Measured and rejected, profiles/r02_lds_dma_loader.txt: the loading wave keeping 3 or 5 rows in flight
+// through LDS-DMA -- global_load_lds_dwordx4 into a ring in LDS, read back with ds_read when due -- instead
+// of 2 rows through registers.  Value-identical, 99 VGPRs, but 6-10 % slower at 8192^2 / 16384^2 and
+// insensitive to the depth: the pass does not wait for the depth of its HBM prefetch.)
+
 // ROLE 0: first wave (HBM -> LDS), 1: middle (LDS -> LDS), 2: last (LDS -> HBM)
 template <class T, int NT, int SPLIT_NW, bool CE_ARR, bool CH_ARR, bool GENERAL, int ROLE, int V>
 __device__ __forceinline__ void split_body(const PassParams<T> &p, const int strip, const int ra,

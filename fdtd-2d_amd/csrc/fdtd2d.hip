@@ -1041,8 +1041,12 @@ int fdtd2d_prepare_run(fdtd2d_t *h, int nsteps, int src_row, int src_col, int wi
     while (left > 0 && rc == 0) {
         int nt = 0, nlev = 0, lo = 0, hi = 0;
         if (!plan_pass(h, left, &nt, &nlev, &lo, &hi)) break;      // single-step kernels: nothing to prepare
-        rc = (nt >= 8 && nlev == nt && (h->boundary == FDTD2D_BOUNDARY_MUR5 || h->pml_split(nt))) ? tune_pass(h, nt, lo, hi, h->top(), h->bottom(), src_row, src_col, with_source != 0)
-                                                                            : warm(nt, lo, hi, nlev);
+        // (a short pass runs on the launch shape of its kernel's full passes: tuned here as well -- inside
+        // fdtd2d_run a one-off tail does not pay for 20-120 ms of trial launches, this call is the set-up)
+        rc = (nt >= 8 && (h->boundary == FDTD2D_BOUNDARY_MUR5 || h->pml_split(nt))) ? tune_pass(h, nt, lo, hi, h->top(), h->bottom(), src_row, src_col, with_source != 0)
+                                                                            : 0;
+        if (!rc && nlev != nt) rc = warm(nt, lo, hi, nlev);
+        else if (!rc && nt < 8) rc = warm(nt, lo, hi, nlev);
         if (nlev == nt && left >= 2 * nt) left %= nt;               // the full passes of a long run are all alike
         else left -= nlev;
     }

@@ -231,16 +231,26 @@ def _pmc_run(counters, child_args, timeout=240):
 
 
 def _dominant(acc, counter):
-    """(kernel name, steady-state mean of `counter`) of the pass kernel with the most dispatches."""
-    best = None
-    for k, d in acc.items():
-        if counter in d and any(t in k for t in ("k_bulk", "k_pass")):
-            if best is None or len(d[counter]) > len(best[1]):
-                best = (k, d[counter])
-    if best is None:
+    """(name of the pass kernel with the most dispatches, steady-state `counter` per PASS): a pass may be
+    several kernels launched once each -- the PML pair k_bulk_split + k_bulk_split_pml, k_zone beside the
+    bulk -- whose counters add up."""
+    cands = {k: d[counter] for k, d in acc.items()
+             if counter in d and any(t in k for t in ("k_bulk", "k_pass", "k_zone"))}
+    if not cands:
         raise RuntimeError(f"no pass kernel with {counter} among {list(acc)[:4]}")
-    v = best[1][len(best[1]) // 2:]           # second half: steady state, shape tuned
-    return best[0], sum(v) / len(v)
+    main = max((k for k in cands if "k_zone" not in k), key=lambda k: len(cands[k]), default=None)
+    if main is None:
+        raise RuntimeError(f"no pass kernel with {counter} among {list(acc)[:4]}")
+    n = len(cands[main])
+    base = lambda k: k.split("<")[0].split("::")[-1].strip()
+    total = 0.0
+    for k, v in cands.items():
+        # launched (about) once per pass, and not another instantiation of the main template (those are the
+        # tuner's trial variants, e.g. 8 waves per strip)
+        if 2 * len(v) >= n and (k == main or base(k) != base(main)):
+            w = v[len(v) // 2:]               # second half: steady state, shape tuned
+            total += sum(w) / len(w)
+    return main, total
 
 
 def measure_traffic(rows, cols, materials, boundary):

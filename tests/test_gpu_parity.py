@@ -391,6 +391,63 @@ def test_rejects_bad_arguments(fd):
         fd.run_fdtd(32, 32, dt=5e-12, nsteps=1)
 
 
+def test_courant_error_code_from_the_c_loop(fd):
+    """fdtd.py:28 at the C boundary: the loop entry points return FDTD2D_E_COURANT (-5) and launch
+    nothing when the Courant number exceeds 1; the half-step entry points (the reference's update_*
+    have no such check) still run."""
+    with fd.Engine(64, 64, dt=5e-12, dx=1e-4, dtype=np.float32) as eng:
+        eng.set_materials()
+        assert eng.courant() > 1.0
+        for call in (lambda: eng.run(4), lambda: eng.prepare(16), lambda: eng.pass_rows(8, 0, 64)):
+            with pytest.raises(fd.Fdtd2dError) as ei:
+                call()
+            assert ei.value.code == -5 and "Courant" in str(ei.value)
+        assert eng.step_count == 0
+        eng.update_h()
+        eng.update_e()
+        assert eng.step_count == 1
+
+
+@pytest.mark.parametrize("tag,dtype", DTYPES)
+def test_device_side_material_scan_and_dtype_conversion(fd, onp, tag, dtype):
+    """set_materials finds min(eps), min(mu) and uniformity on the device (k_minmax); upload / download
+    convert between host and engine types on the device (k_convert2d) with one rounding per element."""
+    r, c = 70, 130
+    rng = np.random.default_rng(3)
+    other = np.float64 if dtype == np.float32 else np.float32
+    eps = (onp.EPS0 * rng.uniform(1, 7, (r, c))).astype(other)
+    mu = np.full((r, c), onp.MU0, other)
+    Ez = rng.standard_normal((r, c)).astype(other)
+    Hx = (rng.standard_normal((r, c - 1)) * 1e-3).astype(other)
+    Hy = (rng.standard_normal((r - 1, c)) * 1e-3).astype(other)
+    with fd.Engine(r, c, DT, DX, dtype=dtype) as eng:
+        eng.set_materials(eps, mu)
+        assert eng.info(9) == 0 and eng.info(10) == 1            # eps array, mu uniform
+        want = (1 / np.sqrt(float(eps.astype(dtype).min()) * float(mu.astype(dtype).min())) * DT) / DX
+        assert eng.courant() == pytest.approx(want, rel=1e-12)
+        eng.upload(Ez, Hx, Hy)
+        got = eng.download(dtype=other)
+        for a, b in zip(got, (Ez, Hx, Hy)):
+            assert a.dtype == other and np.array_equal(a, b.astype(dtype).astype(other))
+        with pytest.raises(fd.Fdtd2dError):
+            eng.set_materials(-eps, mu)
+
+
+def test_dropin_material_cache_sees_in_place_edits(fd, onp):
+    """The per-call drop-ins keep an engine between calls and resend eps/mu when their CONTENT changes:
+    moving a structure inside the same eps buffer keeps the sum and the [0,0] cell, and must still be seen."""
+    r, c = 40, 48
+    rng = np.random.default_rng(9)
+    Ez, Hx, Hy, eps, mu = _random_state(rng, r, c, np.float64, onp)
+    for shift in (0, 5):
+        eps[1:, 1:] = np.roll(eps[1:, 1:], shift, axis=1)          # same buffer, same sum, same eps[0,0]
+        got = fd.update_Ez(Ez.copy(), Hx, Hy, mu, eps, DT, DX)
+        ref = Ez.copy()
+        onp.update_e(ref, Hx, Hy, mu, eps, DT, DX)
+        assert np.array_equal(got, ref), shift
+    fd.invalidate_cache()
+
+
 # ---- temporally blocked passes (k_stream + k_zone) vs single-step kernels vs oracle ----------------
 
 PASS_SHAPES = [(44, 16), (45, 64), (64, 240), (64, 241), (100, 256), (90, 300), (70, 497),

@@ -504,7 +504,7 @@ int create_impl(fdtd2d_t **out, int rows, int cols, int row0, int nrows, int hal
             return bail(fail(h, FDTD2D_E_NOMEM, "hipMalloc of the PML arrays failed"));
     }
 #ifdef FDTD2D_TRACE
-    if (hipMalloc(&h->trace_dev, (size_t)(1 << 16) * 32) != hipSuccess)
+    if (hipMalloc(&h->trace_dev, (size_t)(1 << 16) * 64) != hipSuccess || hipMemset(h->trace_dev, 0, (size_t)(1 << 16) * 64) != hipSuccess)
         return bail(fail(h, FDTD2D_E_NOMEM, "hipMalloc of the trace buffer failed"));
 #endif
     rc = zero_fields(h);
@@ -1245,11 +1245,12 @@ int fdtd2d_sync(fdtd2d_t *h)
 #ifdef FDTD2D_TRACE      // profiling build: dump the stamps of the last level-split launch
     if (const char *path = std::getenv("FDTD2D_TRACE_FILE")) {
         if (h->trace_blocks > 0) {
-            std::vector<unsigned long long> t((size_t)h->trace_blocks * 4);
+            std::vector<unsigned long long> t((size_t)h->trace_blocks * 8);
             HIPCHK(h, hipMemcpy(t.data(), h->trace_dev, t.size() * 8, hipMemcpyDeviceToHost));
             if (FILE *f = std::fopen(path, "w")) {
                 for (long long b = 0; b < h->trace_blocks; ++b)
-                    std::fprintf(f, "%lld %llu %llu %llu %llu\n", b, t[4 * b], t[4 * b + 1], t[4 * b + 2], t[4 * b + 3]);
+                    std::fprintf(f, "%lld %llu %llu %llu %llu %llu %llu %llu %llu\n", b, t[8 * b], t[8 * b + 1], t[8 * b + 2],
+                                 t[8 * b + 3], t[8 * b + 4], t[8 * b + 5], t[8 * b + 6], t[8 * b + 7]);
                 std::fclose(f);
             }
         }

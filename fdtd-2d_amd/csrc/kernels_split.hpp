@@ -126,6 +126,11 @@ constexpr int HAND_DEPTH = 2;
 // of 2 rows through registers.  Value-identical, 99 VGPRs, but 6-10 % slower at 8192^2 / 16384^2 and
 // insensitive to the depth: the pass does not wait for the depth of its HBM prefetch.)
 
+// (Per-wave barrier waits, profiles/r02_trace_barrier.txt: the loading wave is the one the others wait for
+// at the tick barrier -- it waits 8-9 % of a workgroup's life, waves 1-3 23-34 %.  Giving it one level fewer
+// and a third row of prefetch, the storing wave one more -- 3 / 4 / 4 / 5 -- was measured and rejected:
+// 158 vs 148.5 us at 4096^2, 1590 vs 1495 at 16384^2: what the loading wave waits for is the data, and the
+// longer last wave then sets the tick.)
 // ROLE 0: first wave (HBM -> LDS), 1: middle (LDS -> LDS), 2: last (LDS -> HBM)
 template <class T, int NT, int SPLIT_NW, bool CE_ARR, bool CH_ARR, bool GENERAL, int ROLE, int V>
 __device__ __forceinline__ void split_body(const PassParams<T> &p, const int strip, const int ra,

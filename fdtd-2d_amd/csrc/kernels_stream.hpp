@@ -74,14 +74,15 @@ template <class T> struct PassParams {
 };
 
 #ifdef FDTD2D_TRACE
-// {start, end} in shader cycles (s_memtime), kind (0 zone tile, 1 edge strip, 2 plain strip) and
-// the hardware id (XCC << 16 | HW_ID: SE, CU, SIMD of wave 0) of every workgroup of a launch.
+// {start, end} in shader cycles (s_memtime), kind (0 zone tile, 1 edge strip, 2 plain strip), the
+// hardware id (XCC << 16 | HW_ID: SE, CU, SIMD of wave 0) of every workgroup of a launch, and the
+// cycles each of its first four waves spent waiting at the tick barrier (8 words per workgroup).
 struct TraceScope {
     unsigned long long *q;
     unsigned long long t0;
     int kind = 0;
     __device__ __forceinline__ TraceScope(unsigned long long *base)
-        : q(base ? base + 4 * (size_t)blockIdx.x : nullptr), t0(__builtin_amdgcn_s_memtime()) {}
+        : q(base ? base + 8 * (size_t)blockIdx.x : nullptr), t0(__builtin_amdgcn_s_memtime()) {}
     __device__ __forceinline__ ~TraceScope()
     {
         if (q && threadIdx.x == 0) {

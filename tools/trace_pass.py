@@ -31,7 +31,7 @@ with fd.Engine(g, g, dtype=np.float32) as e:
     ms = np.sort(e.time_launches(16, N))
     e.sync()
     shape = (e.info(19), e.info(20))
-t = np.loadtxt(path, dtype=np.uint64).reshape(-1, 5)
+t = np.loadtxt(path, dtype=np.uint64).reshape(-1, 9)
 os.remove(path)
 t0, t1, kind, hw = t[:, 1].astype(np.int64), t[:, 2].astype(np.int64), t[:, 3].astype(int), t[:, 4].astype(np.int64)
 xcc = hw >> 16
@@ -49,6 +49,13 @@ for k, name in ((0, "zone tiles"), (1, "edge strips"), (2, "plain strips")):
         d = (t1 - t0)[m]
         print(f"  {name:13s} n={m.sum():5d} lifetime mean {d.mean():9.0f} min {d.min():9d} max {d.max():9d} cycles; "
               f"starts: {np.percentile(t0[m], [0, 50, 100]).astype(int)}  ends: {np.percentile(t1[m], [0, 50, 100]).astype(int)}")
+# barrier waits per wave role (plain strips): which wave do the others wait for?
+m = kind == 2
+if m.any():
+    life = (t1 - t0)[m].astype(np.float64)
+    for w in range(4):
+        bw = t[:, 5 + w].astype(np.float64)[m]
+        print(f"  plain strips, wave {w}: waits at the tick barrier {100 * (bw / life).mean():5.1f} % of the workgroup's lifetime")
 # resident workgroups over time
 ts = np.linspace(0, span, 21)
 res = [int(((t0 <= x) & (t1 > x)).sum()) for x in ts]

@@ -167,6 +167,9 @@ __device__ __forceinline__ void split_body(const PassParams<T> &p, const int str
     // hand-off ring: [hand-off h][slot d][field][lane]
     auto buf = [&](int h, int d, int field) { return lds + ((h * HAND_DEPTH + d) * NF + field) * 64 + lane; };
 
+#ifdef FDTD2D_TRACE
+    unsigned long long trace_bar = 0;       // cycles this wave waits at the tick barrier (profiling build)
+#endif
     Row slot[S];
 #pragma unroll
     for (int k = 0; k < S; ++k)
@@ -241,9 +244,18 @@ __device__ __forceinline__ void split_body(const PassParams<T> &p, const int str
                 if (CE_ARR) *buf(w, d, 3) = f.ce;
                 if (CH_ARR) *buf(w, d, NF - 1) = f.ch;
             }
+#ifdef FDTD2D_TRACE
+            const unsigned long long tb0 = __builtin_amdgcn_s_memtime();
             __syncthreads();
+            trace_bar += __builtin_amdgcn_s_memtime() - tb0;
+#else
+            __syncthreads();
+#endif
         }
     }
+#ifdef FDTD2D_TRACE
+    if (p.trace && lane == 0 && w < 4) p.trace[8 * (size_t)blockIdx.x + 4 + w] = trace_bar;
+#endif
 }
 
 // FUSE: the zone tiles are the first workgroups of the launch and share its LDS allocation (a

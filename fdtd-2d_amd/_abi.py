@@ -65,6 +65,7 @@ SIGNATURES = {
     "fdtd2d_halo_unpack": (_i, [_vp, _i, _vp]),
     "fdtd2d_slab_attach": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fdtd2d_rccl_unique_id": (_i, [_vp]),
+    "fdtd2d_rccl_selftest": (_i, [_i, _ll]),
     "fdtd2d_slab_attach_rccl": (_i, [_vp, _vp, _i, _i]),
     "fdtd2d_slab_detach": (_i, [_vp]),
     "fdtd2d_run_slab": (_i, [_vp, _i, _i, _i, _i, _i, C.POINTER(_d)]),

@@ -13,6 +13,7 @@
 #include <dlfcn.h>
 
 #include <cstring>
+#include <vector>
 
 using namespace fdtd_host;
 
@@ -68,12 +69,17 @@ int rccl_exchange(void *ctx, void *send_top, void *recv_top, void *send_bot, voi
     return rc ? rc : rc2;
 }
 
+// The process may already hold an RCCL (torch.distributed's "nccl" backend loads the copy that ships with
+// torch): take THAT one -- two RCCL builds in one process would each export the same symbols -- and load the
+// system's library only when none is there yet.
 void *load_rccl(std::string *err)
 {
-    for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-        if (void *l = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) return l;
-    }
-    *err = dlerror() ? dlerror() : "librccl.so not found";
+    for (const char *name : {"librccl.so.1", "librccl.so"})
+        if (void *l = dlopen(name, RTLD_NOW | RTLD_NOLOAD)) return l;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"})
+        if (void *l = dlopen(name, RTLD_NOW | RTLD_LOCAL)) return l;
+    const char *e = dlerror();
+    *err = e ? e : "librccl.so not found";
     return nullptr;
 }
 
@@ -167,6 +173,59 @@ int fdtd2d_rccl_unique_id(void *out128)
     if (!get) return fail(nullptr, FDTD2D_E_NODEVICE, "ncclGetUniqueId not found in librccl.so");
     const int rc = get(out128);                 // ncclUniqueId is 128 bytes
     return rc ? fail(nullptr, FDTD2D_E_STATE, "ncclGetUniqueId failed with code %d", rc) : 0;
+}
+
+// One-rank communicator, one grouped ncclSend / ncclRecv to itself on a non-blocking stream: the same
+// entry points, argument types and enum values as rccl_exchange() above, runnable on a single GPU.
+int fdtd2d_rccl_selftest(int device, long long count)
+{
+    if (count < 1) return FDTD2D_E_ARG;
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, FDTD2D_E_NODEVICE, "hipSetDevice(%d) failed", device);
+    std::string err;
+    void *lib = load_rccl(&err);
+    if (!lib) return fail(nullptr, FDTD2D_E_NODEVICE, "cannot load librccl.so: %s", err.c_str());
+    struct Id { char b[128]; } id;
+    fdtd2d_slab s;
+    auto get = (int (*)(void *))dlsym(lib, "ncclGetUniqueId");
+    auto init = (int (*)(void **, int, Id, int))dlsym(lib, "ncclCommInitRank");
+    s.p_send = (decltype(s.p_send))dlsym(lib, "ncclSend");
+    s.p_recv = (decltype(s.p_recv))dlsym(lib, "ncclRecv");
+    s.p_gstart = (decltype(s.p_gstart))dlsym(lib, "ncclGroupStart");
+    s.p_gend = (decltype(s.p_gend))dlsym(lib, "ncclGroupEnd");
+    s.p_destroy = (decltype(s.p_destroy))dlsym(lib, "ncclCommDestroy");
+    if (!get || !init || !s.p_send || !s.p_recv || !s.p_gstart || !s.p_gend || !s.p_destroy)
+        return fail(nullptr, FDTD2D_E_NODEVICE, "librccl.so lacks the point-to-point entry points");
+    int nrc = get(&id);
+    if (!nrc) nrc = init(&s.comm, 1, id, 0);
+    if (nrc) return fail(nullptr, FDTD2D_E_STATE, "RCCL communicator set-up failed with code %d", nrc);
+    int rc = 0;
+    float *a = nullptr, *b = nullptr;
+    hipStream_t st = nullptr;
+    std::vector<float> host((size_t)count);
+    for (long long n = 0; n < count; ++n) host[(size_t)n] = (float)(n % 8191) * 0.5f;
+    if (hipMalloc(&a, (size_t)count * 4) != hipSuccess || hipMalloc(&b, (size_t)count * 4) != hipSuccess ||
+        hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess ||
+        hipMemcpy(a, host.data(), (size_t)count * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemset(b, 0, (size_t)count * 4) != hipSuccess)
+        rc = fail(nullptr, FDTD2D_E_NOMEM, "self-test buffers");
+    if (!rc) {
+        nrc = s.p_gstart();
+        if (!nrc) nrc = s.p_send(a, (size_t)count, 7, 0, s.comm, st);
+        if (!nrc) nrc = s.p_recv(b, (size_t)count, 7, 0, s.comm, st);
+        const int nrc2 = s.p_gend();
+        if (nrc || nrc2) rc = fail(nullptr, FDTD2D_E_STATE, "grouped ncclSend / ncclRecv failed with code %d", nrc ? nrc : nrc2);
+    }
+    if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = fail(nullptr, FDTD2D_E_STATE, "stream sync after the transfer failed");
+    if (!rc) {
+        std::vector<float> back((size_t)count);
+        if (hipMemcpy(back.data(), b, (size_t)count * 4, hipMemcpyDeviceToHost) != hipSuccess || back != host)
+            rc = fail(nullptr, FDTD2D_E_STATE, "the received message differs from the one sent");
+    }
+    if (st) (void)hipStreamDestroy(st);
+    if (a) (void)hipFree(a);
+    if (b) (void)hipFree(b);
+    s.p_destroy(s.comm);
+    return rc;
 }
 
 int fdtd2d_slab_attach_rccl(fdtd2d_t *h, const void *unique_id128, int rank, int world)

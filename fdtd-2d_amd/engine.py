@@ -358,6 +358,15 @@ class Engine:
             raise _abi.Fdtd2dError(rc, lib.fdtd2d_last_error(None).decode())
         return buf.raw
 
+    @staticmethod
+    def rccl_selftest(device: int = 0, count: int = 1 << 18) -> None:
+        """One-rank RCCL communicator + a grouped ncclSend / ncclRecv to itself through the entry
+        points the slab loop's built-in transport uses (runs on a single GPU); raises on failure."""
+        lib = _abi.load()
+        rc = lib.fdtd2d_rccl_selftest(int(device), int(count))
+        if rc:
+            raise _abi.Fdtd2dError(rc, lib.fdtd2d_last_error(None).decode())
+
     def run_slab(self, nsteps, cycle, overlap, src_row=0, src_col=0, amps=None):
         ap = None
         if amps is not None:

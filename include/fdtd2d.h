@@ -281,6 +281,9 @@ typedef int (*fdtd2d_exchange_fn)(void *ctx, void *send_top, void *recv_top, voi
 int fdtd2d_slab_attach(fdtd2d_t *h, void *send_top, void *recv_top, void *send_bottom, void *recv_bottom,
                        fdtd2d_exchange_fn fn, void *ctx);
 int fdtd2d_rccl_unique_id(void *out128);
+/* Self-test of the built-in transport's glue on ONE GPU: a one-rank communicator and one grouped
+ * ncclSend / ncclRecv of `count` floats to itself through the same entry points.  0 = the message arrived. */
+int fdtd2d_rccl_selftest(int device, long long count);
 int fdtd2d_slab_attach_rccl(fdtd2d_t *h, const void *unique_id128, int rank, int world);
 int fdtd2d_slab_detach(fdtd2d_t *h);
 int fdtd2d_run_slab(fdtd2d_t *h, int nsteps, int cycle, int overlap, int src_row, int src_col,

@@ -126,3 +126,30 @@ def test_gpu_slabs_pml_match_single_engine(tmp_path, options, n, loop):
     assert np.abs(one[0]).max() > 0
     for a, b, k in zip(got, one, ("Ez", "Hx", "Hy")):
         assert np.array_equal(a, b), k
+
+
+@pytest.mark.parametrize("with_torch", [False, True])
+def test_rccl_transport_glue_on_one_gpu(with_torch):
+    """The built-in transport of the C loop (dlopen of librccl, ncclCommInitRank, grouped ncclSend / ncclRecv on
+    a non-blocking stream, ncclFloat32) cannot run between ranks on a one-GPU box; its glue can: a one-rank
+    communicator sending to itself.  with_torch: torch.distributed's "nccl" process group is up first, so the
+    library must pick up the RCCL copy torch already loaded (what a real multi-GPU job looks like)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pre = ""
+    if with_torch:
+        pre = ("import torch, torch.distributed as dist\n"
+               "dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29653', rank=0, world_size=1, "
+               "device_id=torch.device('cuda', 0))\n"
+               "t = torch.ones(4, device='cuda'); dist.all_reduce(t); torch.cuda.synchronize()\n")
+    code = (f"import sys; sys.path.insert(0, {root!r})\n" + pre +
+            "import fdtd2d_amd as fd\n"
+            "fd.Engine.rccl_selftest(0, 3 * 16 * 4096)\n"          # one 16-row halo message of a 4096-column slab
+            "libs = [l.split()[-1] for l in open('/proc/self/maps') if 'librccl' in l]\n"
+            "print('RCCL_OK', sorted(set(libs)))\n")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert p.returncode == 0 and "RCCL_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("RCCL_OK")][-1]
+    assert line.count("librccl") == 1, "two RCCL builds in one process: " + line

@@ -34,7 +34,8 @@ with fd.Engine(g, g, dtype=np.float32) as e:
 t = np.loadtxt(path, dtype=np.uint64).reshape(-1, 9)
 os.remove(path)
 t0, t1, kind, hw = t[:, 1].astype(np.int64), t[:, 2].astype(np.int64), t[:, 3].astype(int), t[:, 4].astype(np.int64)
-xcc = hw >> 16
+xcc = hw >> 32
+hw = hw & 0xffffffff
 for x in np.unique(xcc):        # s_memtime is a per-XCD counter: align every XCD at its first workgroup
     m = xcc == x
     base = t0[m].min()
@@ -56,6 +57,10 @@ if m.any():
     for w in range(4):
         bw = t[:, 5 + w].astype(np.float64)[m]
         print(f"  plain strips, wave {w}: waits at the tick barrier {100 * (bw / life).mean():5.1f} % of the workgroup's lifetime")
+# where the hardware puts wave 0 of a workgroup: SIMD, wave slot, workgroup slot (HW_ID bits 5:4, 3:0, 19:16)
+for name, sh, msk in (("SIMD of wave 0", 4, 3), ("wave slot of wave 0", 0, 15), ("workgroup slot (TG_ID)", 16, 15)):
+    vals, cnt = np.unique((hw[kind == 2] >> sh) & msk, return_counts=True)
+    print(f"  plain strips, {name}: " + ", ".join(f"{int(v)}: {int(c)}" for v, c in zip(vals, cnt)))
 # resident workgroups over time
 ts = np.linspace(0, span, 21)
 res = [int(((t0 <= x) & (t1 > x)).sum()) for x in ts]

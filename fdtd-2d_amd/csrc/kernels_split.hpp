@@ -62,70 +62,52 @@ template <class T, bool GENERAL, bool CE_ARR, bool CH_ARR, int V> struct StripMa
     // row i: level t-1 -> t, in place.  nx = row i+1 at level t-1, pvx = Hx of row i-1 at level t
     __device__ __forceinline__ void level(Row &c, const VT &nxe, const VT &pvx, int t, int i) const
     {
-        if constexpr (!GENERAL) {
-            // Plain strips: the same operations stage by stage -- eight independent differences, eight
-            // products, eight sums ... -- instead of three-instruction chains through one temporary, with the
-            // two cross-lane operands folded into v_sub_f32_dpp forms that start on 8-byte boundaries
-            // (diff_next / diff_prev; a misplaced DPP form stalls the SIMD, kernels_stream.hpp).  44 VALU
-            // instructions per 4 cells and level; sched_barrier keeps the stages in this order.
-            VT dx, dy;
-            dy.v[V - 1] = diff_next(c.e.v[0], c.e.v[V - 1]);       // Ez[i, j+1] - Ez[i, j] across the lane edge
-#pragma unroll
-            for (int v = 0; v < V; ++v) dx.v[v] = nxe.v[v] - c.e.v[v];
-#pragma unroll
-            for (int v = 0; v + 1 < V; ++v) dy.v[v] = c.e.v[v + 1] - c.e.v[v];
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int v = 0; v < V; ++v) {
-                const T ch = CH_ARR ? c.ch.v[v] : p.ch_u;
-                dx.v[v] = ch * dx.v[v];
-                dy.v[v] = ch * dy.v[v];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int v = 0; v < V; ++v) {
-                c.x.v[v] = c.x.v[v] - dx.v[v];
-                c.y.v[v] = c.y.v[v] + dy.v[v];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int v = 0; v < V; ++v) dx.v[v] = c.x.v[v] - pvx.v[v];
-#pragma unroll
-            for (int v = 1; v < V; ++v) dy.v[v] = c.y.v[v] - c.y.v[v - 1];
-            __builtin_amdgcn_sched_barrier(0);        // (the DPP read of Hy comes >= 2 instructions after its write)
-            dy.v[0] = diff_prev(c.y.v[0], c.y.v[V - 1]);           // Hy[i, j] - Hy[i, j-1] across the lane edge
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int v = 0; v < V; ++v) dy.v[v] = dy.v[v] - dx.v[v];
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int v = 0; v < V; ++v) dy.v[v] = dy.v[v] * (CE_ARR ? c.ce.v[v] : p.ce_u);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int v = 0; v < V; ++v) c.e.v[v] = c.e.v[v] + dy.v[v];
-            __builtin_amdgcn_sched_barrier(0);
-            return;
-        }
-        const T e_next_lane = from_next(c.e.v[0]);
+        // The same operations as everywhere else, stage by stage -- eight independent differences, eight
+        // products, eight sums ... -- instead of three-instruction chains through one temporary, with the two
+        // cross-lane operands folded into v_sub_f32_dpp forms written out at fixed places of that order
+        // (diff_next / diff_prev, kernels_stream.hpp).  44 VALU instructions per 4 cells and level on plain
+        // strips; sched_barrier keeps the stages in this order.
         VT po;
         if (GENERAL) po = c.e;
+        VT dx, dy;
+        dy.v[V - 1] = diff_next(c.e.v[0], c.e.v[V - 1]);           // Ez[i, j+1] - Ez[i, j] across the lane edge
+#pragma unroll
+        for (int v = 0; v < V; ++v) dx.v[v] = nxe.v[v] - c.e.v[v];
+#pragma unroll
+        for (int v = 0; v + 1 < V; ++v) dy.v[v] = c.e.v[v + 1] - c.e.v[v];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int v = 0; v < V; ++v) {
             const T ch = CH_ARR ? c.ch.v[v] : (GENERAL ? chu.v[v] : p.ch_u);
-            const T right = (v + 1 < V) ? c.e.v[v + 1] : e_next_lane;
-            c.x.v[v] = c.x.v[v] - ch * (nxe.v[v] - c.e.v[v]);
-            c.y.v[v] = c.y.v[v] + ch * (right - c.e.v[v]);
+            dx.v[v] = ch * dx.v[v];
+            dy.v[v] = ch * dy.v[v];
         }
-        const T hy_prev_lane = from_prev(c.y.v[V - 1]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-            const T ce = CE_ARR ? c.ce.v[v] : (GENERAL ? ceu.v[v] : p.ce_u);
-            const T left = (v > 0) ? c.y.v[v - 1] : hy_prev_lane;
-            c.e.v[v] = c.e.v[v] + ((c.y.v[v] - left) - (c.x.v[v] - pvx.v[v])) * ce;
+            c.x.v[v] = c.x.v[v] - dx.v[v];
+            c.y.v[v] = c.y.v[v] + dy.v[v];
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int v = 0; v < V; ++v) dx.v[v] = c.x.v[v] - pvx.v[v];
+#pragma unroll
+        for (int v = 1; v < V; ++v) dy.v[v] = c.y.v[v] - c.y.v[v - 1];
+        __builtin_amdgcn_sched_barrier(0);            // (the DPP read of Hy comes >= 2 instructions after its write)
+        dy.v[0] = diff_prev(c.y.v[0], c.y.v[V - 1]);               // Hy[i, j] - Hy[i, j-1] across the lane edge
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int v = 0; v < V; ++v) dy.v[v] = dy.v[v] - dx.v[v];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int v = 0; v < V; ++v) dy.v[v] = dy.v[v] * (CE_ARR ? c.ce.v[v] : (GENERAL ? ceu.v[v] : p.ce_u));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int v = 0; v < V; ++v) c.e.v[v] = c.e.v[v] + dy.v[v];
+        __builtin_amdgcn_sched_barrier(0);
         if (GENERAL) {
             if (has_l) {
-                const T a_next = from_next(c.e.v[0]);
+                const T a_next = from_next(c.e.v[0]), e_next_lane = from_next(po.v[0]);
                 VT out;
 #pragma unroll
                 for (int v = 0; v < V; ++v) {

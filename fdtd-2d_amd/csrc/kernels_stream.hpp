@@ -122,16 +122,17 @@ __device__ __forceinline__ float from_next(float x) { return __builtin_bit_cast(
 __device__ __forceinline__ float from_prev(float x) { return __builtin_bit_cast(float, dpp_prev(__builtin_bit_cast(int, x))); }
 // diff_next(a, b) = a of lane l+1  -  b;  diff_prev(a, b) = a  -  b of lane l-1  (one instruction each for float).
 // The CALLER keeps two instructions between a VALU write of the shifted operand and these (no s_nop inside).
+#define DPP_PRE ".p2align 3\n\t"
 __device__ __forceinline__ float diff_next(float a, float b)
 {
     float r;
-    asm volatile(".p2align 3\n\tv_sub_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(a), "v"(b));
+    asm volatile(DPP_PRE "v_sub_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
 __device__ __forceinline__ float diff_prev(float a, float b)
 {
     float r;
-    asm volatile(".p2align 3\n\tv_subrev_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(b), "v"(a));
+    asm volatile(DPP_PRE "v_subrev_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(b), "v"(a));
     return r;
 }
 __device__ __forceinline__ double from_next(double x)

@@ -46,6 +46,7 @@ struct fdtd2d {
     void *ezxb[2] = {nullptr, nullptr};   // PML only: the x-part of the split Ez (set follows hcur)
     void *pml = nullptr;                  // PML only: 4 row + 4 column factor arrays, back to back
     bool have_pml = false;
+    bool pml_unit_outside = false;        // the factor arrays equal 1 outside the layer (checked by fdtd2d_set_pml)
     int pml_L = 0;
     int pml_short_rows = 16;     // band height of the layer waves (8-step k_pass_pml)
     int pml_layer_rows = 64;     // band height of the layer workgroups (16-step k_bulk_split_pml)
@@ -109,7 +110,8 @@ struct fdtd2d {
     // 16-step PML passes: the level-split pair k_bulk_split / k_bulk_split_pml (float32, uniform mu)
     bool pml_split(int nt) const
     {
-        return boundary == FDTD2D_BOUNDARY_PML && nt == 16 && dtype == FDTD2D_F32 && ch_uniform && have_pml;
+        return boundary == FDTD2D_BOUNDARY_PML && nt == 16 && dtype == FDTD2D_F32 && ch_uniform && have_pml &&
+               pml_unit_outside;
     }
     bool use_level_split(int nt, int band_lo, int band_hi) const
     {

@@ -727,6 +727,22 @@ int fdtd2d_set_pml(fdtd2d_t *h, const void *row_factors, const void *col_factors
     if (layer_cells < 1 || 2 * layer_cells + 3 > std::min(h->rows, h->cols))
         return fail(h, FDTD2D_E_ARG, "a %d-cell layer does not fit a %dx%d grid", layer_cells, h->rows, h->cols);
     h->pml_L = layer_cells;
+    // The 16-step pair runs the reference's own update wherever its 16-step cone stays clear of the layer,
+    // and inside the layer kernel on rows / strips outside the layers: both are the split update only if
+    // every factor is exactly 1 there -- H factors on L .. n-2-L (half-cell positions), E factors on
+    // L .. n-1-L.  Arrays without that structure keep the 8-step kernel, which reads them everywhere.
+    auto unit_outside = [&](const void *fac, int n) {
+        auto at = [&](int which, int i) {
+            return h->dtype == FDTD2D_F32 ? (double)((const float *)fac)[(size_t)which * n + i]
+                                           : ((const double *)fac)[(size_t)which * n + i];
+        };
+        for (int i = layer_cells; i <= n - 1 - layer_cells; ++i) {
+            if (i <= n - 2 - layer_cells && (at(0, i) != 1.0 || at(1, i) != 1.0)) return false;    // ah, bh
+            if (at(2, i) != 1.0 || at(3, i) != 1.0) return false;                                   // ae, be
+        }
+        return true;
+    };
+    h->pml_unit_outside = unit_outside(row_factors, h->rows) && unit_outside(col_factors, h->cols);
     int rc = use_device(h);
     if (rc) return rc;
     char *d = (char *)h->pml;
@@ -936,9 +952,10 @@ static int tune_pass(fdtd2d *h, int nt, int lo, int hi, bool zt, bool zb, int sr
         for (int br : ladder)
             if (br * 4 <= hi - lo) cand.push_back({br, both_nw ? nw : 0});
     }
-    if (h->pml_split(nt))                       // the PML pair: plain band height x layer band height
-        for (int br : ladder)
-            if (br * 4 <= hi - lo) cand.push_back({br, 0, 128});
+    if (h->pml_split(nt))                       // the PML pair: plain band height x band height of the layer's end strips
+        for (int re : {128, 256})
+            for (int br : ladder)
+                if (br * 4 <= hi - lo && re * 4 <= hi - lo) cand.push_back({br, 0, re});
     // Shapes that fill the GPU's workgroup slots in k whole rounds, with the first / last strip
     // (~2x the work per row) cut into shorter bands: a launch lasts as long as its longest-lived
     // workgroup, and one that needs 1.1 rounds lasts as long as two.  The zone tiles come first in

@@ -23,13 +23,16 @@ namespace fdtd {
 
 // which (band, strip) tasks the layer kernel owns: strips [0, n_left) and [nstrips - n_right, nstrips)
 // over all bands of `rows_e` rows, the strips between them over the rows [band_lo, a_hi) and
-// [c_lo, band_hi) in bands of `rows_e` rows
+// [c_lo, band_hi) in bands of `rows_tb` rows (one band each where the slab owns the grid's top / bottom: the
+// rows a 16-step cone from the layer reaches, not rounded up to the edge strips' band height -- two 64-row
+// bands per end cost 230 ticks for 73 needed rows, one 80-row band 131)
 template <class T> struct PmlSplit {
     PmlFactors<T> f;
     const T *ezx_in;
     T *ezx_out;
     int n_left, n_right;       // layer strips at the left / right end
-    int rows_e;                // band height of the layer tasks
+    int rows_e;                // band height of the layer tasks of the end strips
+    int rows_tb;               // band height of the top / bottom tasks of the strips between them
     int a_hi, c_lo;            // rows [band_lo, a_hi) and [c_lo, band_hi) belong to the layer kernel in every strip
     int n_all, n_top, n_bot;   // bands per edge strip / top bands / bottom bands per inner strip
 };
@@ -44,11 +47,13 @@ template <class T, bool CE_ARR, int V> struct PmlStripMath {
     const PmlFactors<T> &f;
     int j0;
     bool ld_ok;
+    bool inner;         // a strip whose columns all lie outside the column layers (uniform per workgroup)
     VT ahc, bhc, aec, bec;
     bool mh[V], me[V], cin[V];
 
-    __device__ __forceinline__ PmlStripMath(const PassParams<T> &pp, const PmlFactors<T> &ff, int x0, int lane)
-        : p(pp), f(ff)
+    __device__ __forceinline__ PmlStripMath(const PassParams<T> &pp, const PmlFactors<T> &ff, int x0, int lane,
+                                            bool inner_strip)
+        : p(pp), f(ff), inner(inner_strip)
     {
         j0 = x0 + V * lane;
         ld_ok = j0 >= 0 && j0 < p.g.C;
@@ -71,6 +76,25 @@ template <class T, bool CE_ARR, int V> struct PmlStripMath {
     __device__ __forceinline__ void level(Row &c, const VT &nxe, const VT &pvx, int t, int i) const
     {
         if (i < 0 || i > p.g.R - 1) return;                         // outside the grid
+        // Rows outside the row layers of a strip outside the column layers: every factor is exactly 1 there
+        // (fdtd2d_set_pml checks the arrays it is given: H factors on rows L .. R-2-L, E factors on L .. R-1-L) and
+        // no cell is in the layer, so the split update IS the reference's (1*x - (1*ch)*d == x - ch*d bit for
+        // bit) and Ezx keeps its value: the plain staged body, 44 instructions instead of ~110, and no factor
+        // loads.  Most rows of the top / bottom tasks are such rows (the task's cone touches the layer, its rows
+        // mostly do not).
+#ifndef FDTD2D_PML_NOFAST
+        if (inner && i >= f.L && i <= f.R - 2 - f.L) {
+            staged_level<T, V>(c.e, c.x, c.y, nxe, pvx, [&](int) { return p.ch_u; },
+                               [&](int v) { return CE_ARR ? c.ce.v[v] : p.ce_u; });
+            if (i >= p.src_row && i < p.src_row1) {
+                const double amp = p.amp[t - 1];
+#pragma unroll
+                for (int v = 0; v < V; ++v)
+                    if (j0 + v >= p.src_col && j0 + v < p.src_col1) c.e.v[v] = (T)((double)c.e.v[v] + amp);
+            }
+            return;
+        }
+#endif
         const T e_next_lane = from_next(c.e.v[0]);
         if (i <= p.g.R - 2) {                                       // H rows 0..R-2
             const T ar = f.ahr[i], br = f.bhr[i];
@@ -113,7 +137,8 @@ template <class T, bool CE_ARR, int V> struct PmlStripMath {
 // the tick loop of split_body (kernels_split.hpp) with four-field rows; see there for the pipeline
 template <class T, int NT, int SPLIT_NW, bool CE_ARR, int ROLE, int V>
 __device__ __forceinline__ void split_body_pml(const PassParams<T> &p, const PmlSplit<T> &q, const int strip,
-                                               const int ra, const int rb, const int w, VecN<T, V> *lds)
+                                               const int ra, const int rb, const int w, VecN<T, V> *lds,
+                                               const bool inner)
 {
     using M = PmlStripMath<T, CE_ARR, V>;
     using Row = typename M::Row;
@@ -126,7 +151,7 @@ __device__ __forceinline__ void split_body_pml(const PassParams<T> &p, const Pml
     const Geom g = p.g;
     const int lane = threadIdx.x & 63;
     const int x0 = strip_x0<T, NT, V>(p, strip);
-    const M m(p, q.f, x0, lane);
+    const M m(p, q.f, x0, lane, inner);
     const int j0 = m.j0;
     const bool st_ok = m.ld_ok && j0 >= strip * OW && j0 < (strip + 1) * OW;
     const size_t col = (size_t)(m.ld_ok ? j0 : 0);
@@ -229,6 +254,7 @@ __global__ __launch_bounds__(64 * SPLIT_NW) void k_bulk_split_pml(const PassPara
     int b = blockIdx.x;
     int strip, ra, rb;
     const int n_edge = q.n_left + q.n_right;
+    const bool inner = b >= n_edge * q.n_all;       // the top / bottom tasks of the strips between the column layers
     if (b < n_edge * q.n_all) {
         const int sidx = b / q.n_all, band = b - sidx * q.n_all;
         strip = sidx < q.n_left ? sidx : p.nstrips - n_edge + sidx;
@@ -240,11 +266,11 @@ __global__ __launch_bounds__(64 * SPLIT_NW) void k_bulk_split_pml(const PassPara
         const int sidx = b / per, band = b - sidx * per;
         strip = q.n_left + sidx;
         if (band < q.n_top) {
-            ra = p.band_lo + band * q.rows_e;
-            rb = min(ra + q.rows_e, q.a_hi);
+            ra = p.band_lo + band * q.rows_tb;
+            rb = min(ra + q.rows_tb, q.a_hi);
         } else {
-            ra = q.c_lo + (band - q.n_top) * q.rows_e;
-            rb = min(ra + q.rows_e, p.band_hi);
+            ra = q.c_lo + (band - q.n_top) * q.rows_tb;
+            rb = min(ra + q.rows_tb, p.band_hi);
         }
     }
     if (ra >= rb) return;
@@ -253,9 +279,9 @@ __global__ __launch_bounds__(64 * SPLIT_NW) void k_bulk_split_pml(const PassPara
 #pragma unroll
         for (int v = 0; v < V; ++v) lds[n].v[v] = T(0);
     __syncthreads();
-    if (w == 0) split_body_pml<T, NT, SPLIT_NW, CE_ARR, 0, V>(p, q, strip, ra, rb, w, lds);
-    else if (w == SPLIT_NW - 1) split_body_pml<T, NT, SPLIT_NW, CE_ARR, 2, V>(p, q, strip, ra, rb, w, lds);
-    else split_body_pml<T, NT, SPLIT_NW, CE_ARR, 1, V>(p, q, strip, ra, rb, w, lds);
+    if (w == 0) split_body_pml<T, NT, SPLIT_NW, CE_ARR, 0, V>(p, q, strip, ra, rb, w, lds, inner);
+    else if (w == SPLIT_NW - 1) split_body_pml<T, NT, SPLIT_NW, CE_ARR, 2, V>(p, q, strip, ra, rb, w, lds, inner);
+    else split_body_pml<T, NT, SPLIT_NW, CE_ARR, 1, V>(p, q, strip, ra, rb, w, lds, inner);
 }
 
 }  // namespace fdtd

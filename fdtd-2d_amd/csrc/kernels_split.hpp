@@ -26,6 +26,53 @@ namespace fdtd {
 // same number of resident waves covers taller bands (less fill per band) -- the better trade on
 // grids that cannot fill the GPU otherwise.
 
+// One level of one row, in place: the reference's operations (main.py:66-76, 12-27), one rounding each, written
+// stage by stage -- eight independent differences, eight products, eight sums ... -- instead of three-instruction
+// chains through one temporary, with the two cross-lane operands folded into v_sub_f32_dpp forms written out at
+// fixed places of that order (diff_next / diff_prev, kernels_stream.hpp).  44 VALU instructions per 4 cells;
+// sched_barrier keeps the stages in this order.  ch(v), ce(v): the coefficients of column v of the lane.
+template <class T, int V, class CH, class CE>
+__device__ __forceinline__ void staged_level(VecN<T, V> &e, VecN<T, V> &x, VecN<T, V> &y, const VecN<T, V> &nxe,
+                                             const VecN<T, V> &pvx, CH ch, CE ce)
+{
+    VecN<T, V> dx, dy;
+    dy.v[V - 1] = diff_next(e.v[0], e.v[V - 1]);                   // Ez[i, j+1] - Ez[i, j] across the lane edge
+#pragma unroll
+    for (int v = 0; v < V; ++v) dx.v[v] = nxe.v[v] - e.v[v];
+#pragma unroll
+    for (int v = 0; v + 1 < V; ++v) dy.v[v] = e.v[v + 1] - e.v[v];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        const T c = ch(v);
+        dx.v[v] = c * dx.v[v];
+        dy.v[v] = c * dy.v[v];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        x.v[v] = x.v[v] - dx.v[v];
+        y.v[v] = y.v[v] + dy.v[v];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int v = 0; v < V; ++v) dx.v[v] = x.v[v] - pvx.v[v];
+#pragma unroll
+    for (int v = 1; v < V; ++v) dy.v[v] = y.v[v] - y.v[v - 1];
+    __builtin_amdgcn_sched_barrier(0);                // (the DPP read of Hy comes >= 2 instructions after its write)
+    dy.v[0] = diff_prev(y.v[0], y.v[V - 1]);                       // Hy[i, j] - Hy[i, j-1] across the lane edge
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int v = 0; v < V; ++v) dy.v[v] = dy.v[v] - dx.v[v];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int v = 0; v < V; ++v) dy.v[v] = dy.v[v] * ce(v);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int v = 0; v < V; ++v) e.v[v] = e.v[v] + dy.v[v];
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // per-lane constants of a strip + the level update (same operations as stream_body)
 template <class T, bool GENERAL, bool CE_ARR, bool CH_ARR, int V> struct StripMath {
     using VT = VecN<T, V>;
@@ -62,49 +109,11 @@ template <class T, bool GENERAL, bool CE_ARR, bool CH_ARR, int V> struct StripMa
     // row i: level t-1 -> t, in place.  nx = row i+1 at level t-1, pvx = Hx of row i-1 at level t
     __device__ __forceinline__ void level(Row &c, const VT &nxe, const VT &pvx, int t, int i) const
     {
-        // The same operations as everywhere else, stage by stage -- eight independent differences, eight
-        // products, eight sums ... -- instead of three-instruction chains through one temporary, with the two
-        // cross-lane operands folded into v_sub_f32_dpp forms written out at fixed places of that order
-        // (diff_next / diff_prev, kernels_stream.hpp).  44 VALU instructions per 4 cells and level on plain
-        // strips; sched_barrier keeps the stages in this order.
         VT po;
         if (GENERAL) po = c.e;
-        VT dx, dy;
-        dy.v[V - 1] = diff_next(c.e.v[0], c.e.v[V - 1]);           // Ez[i, j+1] - Ez[i, j] across the lane edge
-#pragma unroll
-        for (int v = 0; v < V; ++v) dx.v[v] = nxe.v[v] - c.e.v[v];
-#pragma unroll
-        for (int v = 0; v + 1 < V; ++v) dy.v[v] = c.e.v[v + 1] - c.e.v[v];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int v = 0; v < V; ++v) {
-            const T ch = CH_ARR ? c.ch.v[v] : (GENERAL ? chu.v[v] : p.ch_u);
-            dx.v[v] = ch * dx.v[v];
-            dy.v[v] = ch * dy.v[v];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int v = 0; v < V; ++v) {
-            c.x.v[v] = c.x.v[v] - dx.v[v];
-            c.y.v[v] = c.y.v[v] + dy.v[v];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int v = 0; v < V; ++v) dx.v[v] = c.x.v[v] - pvx.v[v];
-#pragma unroll
-        for (int v = 1; v < V; ++v) dy.v[v] = c.y.v[v] - c.y.v[v - 1];
-        __builtin_amdgcn_sched_barrier(0);            // (the DPP read of Hy comes >= 2 instructions after its write)
-        dy.v[0] = diff_prev(c.y.v[0], c.y.v[V - 1]);               // Hy[i, j] - Hy[i, j-1] across the lane edge
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int v = 0; v < V; ++v) dy.v[v] = dy.v[v] - dx.v[v];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int v = 0; v < V; ++v) dy.v[v] = dy.v[v] * (CE_ARR ? c.ce.v[v] : (GENERAL ? ceu.v[v] : p.ce_u));
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int v = 0; v < V; ++v) c.e.v[v] = c.e.v[v] + dy.v[v];
-        __builtin_amdgcn_sched_barrier(0);
+        staged_level<T, V>(
+            c.e, c.x, c.y, nxe, pvx, [&](int v) { return CH_ARR ? c.ch.v[v] : (GENERAL ? chu.v[v] : p.ch_u); },
+            [&](int v) { return CE_ARR ? c.ce.v[v] : (GENERAL ? ceu.v[v] : p.ce_u); });
         if (GENERAL) {
             if (has_l) {
                 const T a_next = from_next(c.e.v[0]), e_next_lane = from_next(po.v[0]);

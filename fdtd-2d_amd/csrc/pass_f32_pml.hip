@@ -23,15 +23,18 @@ template <bool CE_ARR> static int launch_pml_split(fdtd2d *h, fdtd::PassParams<f
     // rows whose 16-step cone can touch the top / bottom layer: [0, L + 1 + 2 NT) and the mirror
     const int reach = L + 1 + 2 * NT;
     const int re = std::max(16, h->shape_now.edge_rows > 0 ? h->shape_now.edge_rows : h->pml_layer_rows);
-    auto up = [&](int x) { return (x + re - 1) / re * re; };
+    auto up8 = [&](int x) { return (x + 7) / 8 * 8; };
     int a_hi = p.band_lo, c_lo = p.band_hi;
     if (inner > 0) {
-        if (h->top()) a_hi = std::min(p.band_hi, p.band_lo + up(std::max(0, reach - p.band_lo)));
-        if (h->bottom()) c_lo = std::max(a_hi, p.band_hi - up(std::max(0, p.band_hi - (R - reach))));
+        if (h->top()) a_hi = std::min(p.band_hi, p.band_lo + up8(std::max(0, reach - p.band_lo)));
+        if (h->bottom()) c_lo = std::max(a_hi, p.band_hi - up8(std::max(0, p.band_hi - (R - reach))));
     }
+    // top / bottom tasks: one band per end (taller ends -- a slab whose halo starts far above the reach -- in
+    // bands of at most 128 rows)
+    const int rtb = std::max(8, std::min(128, std::max(a_hi - p.band_lo, p.band_hi - c_lo)));
     fdtd::PmlSplit<T> q{pml_factors<T>(h), (const T *)h->ezxb[h->hcur], (T *)h->ezxb[h->hcur ^ 1],
-                        n_left, n_right, re, a_hi, c_lo, (region + re - 1) / re,
-                        (a_hi - p.band_lo + re - 1) / re, (p.band_hi - c_lo + re - 1) / re};
+                        n_left, n_right, re, rtb, a_hi, c_lo, (region + re - 1) / re,
+                        (a_hi - p.band_lo + rtb - 1) / rtb, (p.band_hi - c_lo + rtb - 1) / rtb};
     const long long layer_blocks = (long long)(n_left + n_right) * q.n_all + (long long)inner * (q.n_top + q.n_bot);
     // the plain kernel: inner strips x the rows between the layer bands, no edge strips, no zones
     fdtd::PassParams<T> pp = p;

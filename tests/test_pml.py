@@ -132,11 +132,13 @@ def test_device_pml_run_fdtd_absorbs():
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("shape,L,arrays", [((96, 130), 20, True), ((200, 301), 40, False), ((150, 600), 30, True),
-                                             ((64, 64), 10, False)])
+                                             ((64, 64), 10, False), ((260, 900), 40, False)])
 def test_device_pml_passes_match_oracle(dtype, shape, L, arrays):
     """PML passes + remainder steps, source inside the layer's cone: 16-step passes on the
     level-split pair k_bulk_split / k_bulk_split_pml (float32; 27 steps = two short passes of 14 and
-    13 levels), 8-step passes on k_pass_pml (3 passes + 3 single steps), single steps only."""
+    13 levels), 8-step passes on k_pass_pml (3 passes + 3 single steps), single steps only.  (150, 600) and
+    (260, 900) have strips between the column layers: the rows of their top / bottom tasks that lie outside the row
+    layers take the plain staged body inside k_bulk_split_pml."""
     import fdtd2d_amd as fd
     from oracle import fdtd_numpy as onp
     from oracle import pml_numpy as pm

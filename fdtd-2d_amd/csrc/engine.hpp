@@ -100,12 +100,13 @@ struct fdtd2d {
     // whole grids (a slab's 16-row halo does not feed them), no probe tile.  One such pass takes
     // 17..20 remaining steps in ONE sweep; it pays where the sweep dominates -- us per run(20) as one
     // 20-step pass vs a 16- and a 4-step pass: 16384^2 1827 vs 2914, 8192^2 870 vs 942, 4096^2 317 vs
-    // 250 (profiles/r02_long_passes.txt) -- hence the size rule (FDTD2D_OPT_MAX_PASS_STEPS = 20 lifts
-    // it, as 16 does for the 16-step rule).
+    // 250 (profiles/r02_long_passes.txt); with the staged level body and a source in the run: 8192^2 617 vs
+    // 626, 6144^2 407 vs 494, 4096^2 249 vs 268, 2048^2 193 vs 127 (profiles/r02_nt20_small.txt) -- hence the
+    // size rule of 16 Mi cells (FDTD2D_OPT_MAX_PASS_STEPS = 20 lifts it, as 16 does for the 16-step rule).
     bool long_passes() const
     {
         if (dtype != FDTD2D_F32 || boundary != FDTD2D_BOUNDARY_MUR5 || max_nt < 20 || probe_cap) return false;
-        return max_nt_forced || (size_t)nrows * cols >= (size_t)64 << 20;
+        return max_nt_forced || (size_t)nrows * cols >= (size_t)16 << 20;
     }
     // 16-step PML passes: the level-split pair k_bulk_split / k_bulk_split_pml (float32, uniform mu)
     bool pml_split(int nt) const

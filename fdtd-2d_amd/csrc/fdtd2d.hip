@@ -1009,9 +1009,13 @@ static int tune_pass(fdtd2d *h, int nt, int lo, int hi, bool zt, bool zb, int sr
     // ring map: 314-row bands x 8 waves 0.53 ms in one-way trials like 157 x 4, 0.57 vs 0.53 ms in a run;
     // profiles/r02_tuner_view.txt).  The current set is kept in a scratch copy meanwhile and put back at the
     // end; without the memory for it the trials stay one-way.
+    // (Not while pieces of a pass are pending -- fdtd2d_pass_rows has already written rows next to the cuts
+    // into the other set, and a trial in the reverse direction would be followed by trials that overwrite
+    // them with later time levels: one-way trials only rewrite this piece's rows with the values they get
+    // anyway.)
     const int cur0 = h->cur, hcur0 = h->hcur;
     std::vector<std::pair<void *, void *>> saved;          // (scratch copy, original)
-    {
+    if (h->pend_nt == 0) {
         std::vector<void *> orig{h->ez[cur0], h->hxb[hcur0], h->hyb[hcur0]};
         if (h->boundary == FDTD2D_BOUNDARY_PML && h->ezxb[hcur0]) orig.push_back(h->ezxb[hcur0]);
         for (void *o : orig) {

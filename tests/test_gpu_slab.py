@@ -32,6 +32,10 @@ DT, DX = 5e-14, 1e-4
     (2, (170, 600), "float32", "array", True, {"max_pass_steps": 16}),
     (2, (170, 600), "float32", "array", True, {"max_pass_steps": 16, "extent": (60, 3)}),
     (3, (180, 520), "float64", "array", True, {"extent": (1, 300)}),
+    # slabs large enough for the launch-shape tuner (>= 4 Mi cells per piece): its trial launches run INSIDE the
+    # first overlapped cycle, after the rows next to the cuts have been issued
+    (2, (2400, 3600), "float32", "uniform", True, {"max_pass_steps": 16, "loop": "c"}),
+    (2, (2400, 3600), "float32", "uniform", True, {"max_pass_steps": 16}),
 ])
 def test_gpu_slabs_match_single_engine_and_oracle(tmp_path, world, shape, dtype, materials, overlap,
                                                   options):

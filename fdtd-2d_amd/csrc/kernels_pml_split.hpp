@@ -82,7 +82,6 @@ template <class T, bool CE_ARR, int V> struct PmlStripMath {
         // bit) and Ezx keeps its value: the plain staged body, 44 instructions instead of ~110, and no factor
         // loads.  Most rows of the top / bottom tasks are such rows (the task's cone touches the layer, its rows
         // mostly do not).
-#ifndef FDTD2D_PML_NOFAST
         if (inner && i >= f.L && i <= f.R - 2 - f.L) {
             staged_level<T, V>(c.e, c.x, c.y, nxe, pvx, [&](int) { return p.ch_u; },
                                [&](int v) { return CE_ARR ? c.ce.v[v] : p.ce_u; });
@@ -94,7 +93,6 @@ template <class T, bool CE_ARR, int V> struct PmlStripMath {
             }
             return;
         }
-#endif
         const T e_next_lane = from_next(c.e.v[0]);
         if (i <= p.g.R - 2) {                                       // H rows 0..R-2
             const T ar = f.ahr[i], br = f.bhr[i];

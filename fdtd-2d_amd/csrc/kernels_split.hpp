@@ -166,6 +166,10 @@ constexpr int HAND_DEPTH = 2;
 // and a third row of prefetch, the storing wave one more -- 3 / 4 / 4 / 5 -- was measured and rejected:
 // 158 vs 148.5 us at 4096^2, 1590 vs 1495 at 16384^2: what the loading wave waits for is the data, and the
 // longer last wave then sets the tick.)
+// (Batched lane shifts, profiles/r02_dpp_alignment.txt: the four Ez shifts of a tick issued together, then the four Hy
+// updates, the four Hy shifts together, then Hx / Ez level by level -- runs of adjacent DPP forms are free in the
+// microbenchmark.  Same values, 118 VGPRs, but 10 % SLOWER at 4096^2 (150.5 vs 136 us), 5 % at 8192^2, 1 % at 16384^2:
+// four cone checks per level instead of one and 4-wide instead of 8-wide stages cost more than the shifts do.)
 // ROLE 0: first wave (HBM -> LDS), 1: middle (LDS -> LDS), 2: last (LDS -> HBM)
 template <class T, int NT, int SPLIT_NW, bool CE_ARR, bool CH_ARR, bool GENERAL, int ROLE, int V>
 __device__ __forceinline__ void split_body(const PassParams<T> &p, const int strip, const int ra,

@@ -258,10 +258,10 @@ __device__ __forceinline__ void split_body(const PassParams<T> &p, const int str
                 if (CE_ARR) in.ce = *buf(w - 1, dr, 3);
                 if (CH_ARR) in.ch = *buf(w - 1, dr, NF - 1);
             }
-            if (r < r_end) {
+            if (__builtin_expect(r < r_end, 1)) {
 #pragma unroll
                 for (int l = 1; l <= LV; ++l) {
-                    if (r < first[l]) continue;             // outside the cone / beyond a short pass
+                    if (__builtin_expect(r < first[l], 0)) continue;     // outside the cone / beyond a short pass
                     Row &c = slot[(k - l + 2 * S) % S];
                     m.level(c, slot[(k - l + 1 + 2 * S) % S].e, slot[(k - l - 1 + 2 * S) % S].x, t0 + l, r - l);
                 }

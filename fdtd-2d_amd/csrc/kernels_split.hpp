@@ -216,14 +216,32 @@ __device__ __forceinline__ void split_body(const PassParams<T> &p, const int str
         for (int v = 0; v < V; ++v)
             slot[k].e.v[v] = slot[k].x.v[v] = slot[k].y.v[v] = slot[k].ce.v[v] = slot[k].ch.v[v] = T(0);
 
+    // Addresses as (row pointer in scalar registers) + (the lane's byte offset, 32 bits, constant over the band):
+    // global_load / global_store take that pair directly; the 64-bit per-lane pointer arithmetic it replaces was 7
+    // VALU instructions per tick in the loading wave -- the wave the others wait for.
+    unsigned lane_off = (unsigned)col * (unsigned)sizeof(T);
+    // (the row pointer goes through an empty asm as a scalar: left alone, the compiler folds the lane offset into a
+    // per-lane copy of the field pointer and adds the row offset with a 64-bit VALU add per access)
+    // (it stays a GLOBAL pointer through the asm -- a generic one would turn the accesses into flat_load / flat_store)
+    typedef const char __attribute__((address_space(1))) *gcptr;
+    auto row_ptr = [&](const T *field, int i) {
+        gcptr rp = (gcptr)(field + at(g, i, 0));
+        asm volatile("" : "+s"(rp));
+        return (const char *)rp;
+    };
+    // (and the lane offset through one as a vector register at each use: hoisted out of the loop as a 64-bit
+    // value it is no longer the zero-extended 32-bit offset the scalar-base addressing form takes)
+    // (in place, so that it keeps its own register: a copy lands in a register of the slot about to be loaded,
+    // and the compiler then waits for that slot's previous load -- the whole prefetch -- before writing it)
+    auto lane_off_now = [&]() { asm volatile("" : "+v"(lane_off)); return lane_off; };
     auto load_global = [&](Row &r, int i) {
         const int ic = min(i, tau1 - 1);
-        const size_t o = at(g, ic, 0) + col;
-        r.e = ldn<V>(p.ez_in + o);
-        r.x = ldn<V>(p.hx_in + o);
-        r.y = ldn<V>(p.hy_in + o);
-        if (CE_ARR) r.ce = ldn<V>(p.ce + o);
-        if (CH_ARR) r.ch = ldn<V>(p.ch + o);
+        const unsigned lo = lane_off_now();
+        r.e = ldn<V>(reinterpret_cast<const T *>(row_ptr(p.ez_in, ic) + lo));
+        r.x = ldn<V>(reinterpret_cast<const T *>(row_ptr(p.hx_in, ic) + lo));
+        r.y = ldn<V>(reinterpret_cast<const T *>(row_ptr(p.hy_in, ic) + lo));
+        if (CE_ARR) r.ce = ldn<V>(reinterpret_cast<const T *>(row_ptr(p.ce, ic) + lo));
+        if (CH_ARR) r.ch = ldn<V>(reinterpret_cast<const T *>(row_ptr(p.ch, ic) + lo));
         if (GENERAL) {
 #pragma unroll
             for (int v = 0; v < V; ++v) {
@@ -269,12 +287,14 @@ __device__ __forceinline__ void split_body(const PassParams<T> &p, const int str
             const Row &f = slot[(k - LV + 2 * S) % S];       // row r - LV, now at level t0 + LV
             if (ROLE == 2) {
                 const int io = r - LV;
-                const bool keep = st_ok && io >= ra && io < rb;
-                const size_t o = at(g, min(max(io, ra), rb - 1), 0) + col;
-                const size_t dd = (size_t)(blockIdx.x % TRASH_SLOTS) * (TRASH_SLOT_BYTES / sizeof(T)) + (size_t)lane * V;
-                stn<V>(keep ? p.ez_out + o : p.trash + dd, f.e);
-                stn<V>(keep ? p.hx_out + o : p.trash + dd + 64 * V, f.x);
-                stn<V>(keep ? p.hy_out + o : p.trash + dd + 128 * V, f.y);
+                if (io >= ra && io < rb) {            // a row of the band (uniform) ...
+                    if (st_ok) {                      // ... and a column this strip owns (lanes masked off otherwise)
+                        const unsigned lo = lane_off_now();
+                        stn<V>(reinterpret_cast<T *>(const_cast<char *>(row_ptr(p.ez_out, io)) + lo), f.e);
+                        stn<V>(reinterpret_cast<T *>(const_cast<char *>(row_ptr(p.hx_out, io)) + lo), f.x);
+                        stn<V>(reinterpret_cast<T *>(const_cast<char *>(row_ptr(p.hy_out, io)) + lo), f.y);
+                    }
+                }
             } else {
                 const int d = tau & 1;
                 *buf(w, d, 0) = f.e;

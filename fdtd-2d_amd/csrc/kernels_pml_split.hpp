@@ -172,19 +172,31 @@ __device__ __forceinline__ void split_body_pml(const PassParams<T> &p, const Pml
     // unconditional loads: rows clamped into what this handle stores (rows outside the grid or the
     // band are never processed), lanes outside the grid zeroed
     const int row_lo = max(tau0, max(0, g.row_base)), row_hi = min(tau1, g.R) - 1;
+    // addresses as scalar row pointer + the lane's 32-bit byte offset, as in split_body (kernels_split.hpp)
+    unsigned lane_off = (unsigned)col * (unsigned)sizeof(T);
+    typedef const char __attribute__((address_space(1))) *gcptr;
+    auto row_ptr = [&](const T *field, int i) {
+        gcptr rp = (gcptr)(field + at(g, i, 0));
+        asm volatile("" : "+s"(rp));
+        return (const char *)rp;
+    };
+    auto lane_off_now = [&]() { asm volatile("" : "+v"(lane_off)); return lane_off; };
     auto load_global = [&](Row &r, int i) {
-        const size_t o = at(g, min(max(i, row_lo), row_hi), 0) + col;
-        r.e = ldn<V>(p.ez_in + o);
-        r.x = ldn<V>(p.hx_in + o);
-        r.y = ldn<V>(p.hy_in + o);
-        r.ex = ldn<V>(q.ezx_in + o);
-        if (CE_ARR) r.ce = ldn<V>(p.ce + o);
+        const int ic = min(max(i, row_lo), row_hi);
+        const unsigned lo = lane_off_now();
+        r.e = ldn<V>(reinterpret_cast<const T *>(row_ptr(p.ez_in, ic) + lo));
+        r.x = ldn<V>(reinterpret_cast<const T *>(row_ptr(p.hx_in, ic) + lo));
+        r.y = ldn<V>(reinterpret_cast<const T *>(row_ptr(p.hy_in, ic) + lo));
+        r.ex = ldn<V>(reinterpret_cast<const T *>(row_ptr(q.ezx_in, ic) + lo));
+        if (CE_ARR) r.ce = ldn<V>(reinterpret_cast<const T *>(row_ptr(p.ce, ic) + lo));
+        if (!inner) {           // (every lane of a strip between the column layers is inside the grid)
 #pragma unroll
-        for (int v = 0; v < V; ++v) {
-            r.e.v[v] = m.ld_ok ? r.e.v[v] : T(0);
-            r.x.v[v] = m.ld_ok ? r.x.v[v] : T(0);
-            r.y.v[v] = m.ld_ok ? r.y.v[v] : T(0);
-            r.ex.v[v] = m.ld_ok ? r.ex.v[v] : T(0);
+            for (int v = 0; v < V; ++v) {
+                r.e.v[v] = m.ld_ok ? r.e.v[v] : T(0);
+                r.x.v[v] = m.ld_ok ? r.x.v[v] : T(0);
+                r.y.v[v] = m.ld_ok ? r.y.v[v] : T(0);
+                r.ex.v[v] = m.ld_ok ? r.ex.v[v] : T(0);
+            }
         }
     };
     if (ROLE == 0) {
@@ -209,10 +221,10 @@ __device__ __forceinline__ void split_body_pml(const PassParams<T> &p, const Pml
                 in.ex = *buf(w - 1, dr, 3);
                 if (CE_ARR) in.ce = *buf(w - 1, dr, 4);
             }
-            if (r < r_end) {
+            if (__builtin_expect(r < r_end, 1)) {
 #pragma unroll
                 for (int l = 1; l <= LV; ++l) {
-                    if (r < first[l]) continue;
+                    if (__builtin_expect(r < first[l], 0)) continue;
                     Row &c = slot[(k - l + 2 * S) % S];
                     m.level(c, slot[(k - l + 1 + 2 * S) % S].e, slot[(k - l - 1 + 2 * S) % S].x, t0 + l, r - l);
                 }
@@ -220,13 +232,15 @@ __device__ __forceinline__ void split_body_pml(const PassParams<T> &p, const Pml
             const Row &f = slot[(k - LV + 2 * S) % S];
             if (ROLE == 2) {
                 const int io = r - LV;
-                const bool keep = st_ok && io >= ra && io < rb;
-                const size_t o = at(g, min(max(io, ra), rb - 1), 0) + col;
-                const size_t dd = (size_t)(blockIdx.x % TRASH_SLOTS) * (TRASH_SLOT_BYTES / sizeof(T)) + (size_t)lane * V;
-                stn<V>(keep ? p.ez_out + o : p.trash + dd, f.e);
-                stn<V>(keep ? p.hx_out + o : p.trash + dd + 64 * V, f.x);
-                stn<V>(keep ? p.hy_out + o : p.trash + dd + 128 * V, f.y);
-                stn<V>(keep ? q.ezx_out + o : p.trash + dd + 192 * V, f.ex);
+                if (io >= ra && io < rb) {            // a row of the band (uniform) ...
+                    if (st_ok) {                      // ... and a column this strip owns (lanes masked off otherwise)
+                        const unsigned lo = lane_off_now();
+                        stn<V>(reinterpret_cast<T *>(const_cast<char *>(row_ptr(p.ez_out, io)) + lo), f.e);
+                        stn<V>(reinterpret_cast<T *>(const_cast<char *>(row_ptr(p.hx_out, io)) + lo), f.x);
+                        stn<V>(reinterpret_cast<T *>(const_cast<char *>(row_ptr(p.hy_out, io)) + lo), f.y);
+                        stn<V>(reinterpret_cast<T *>(const_cast<char *>(row_ptr(q.ezx_out, io)) + lo), f.ex);
+                    }
+                }
             } else {
                 const int d = tau & 1;
                 *buf(w, d, 0) = f.e;

@@ -35,6 +35,22 @@ template <class T, int V, class CH, class CE>
 __device__ __forceinline__ void staged_level(VecN<T, V> &e, VecN<T, V> &x, VecN<T, V> &y, const VecN<T, V> &nxe,
                                              const VecN<T, V> &pvx, CH ch, CE ce)
 {
+    if constexpr (sizeof(T) == 8) {         // float64: the chained form, lane shifts placed by the compiler (kernels_stream.hpp)
+        const T e_next_lane = from_next(e.v[0]);
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const T c = ch(v);
+            const T right = (v + 1 < V) ? e.v[v + 1] : e_next_lane;
+            x.v[v] = x.v[v] - c * (nxe.v[v] - e.v[v]);
+            y.v[v] = y.v[v] + c * (right - e.v[v]);
+        }
+        const T hy_prev_lane = from_prev(y.v[V - 1]);
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const T left = (v > 0) ? y.v[v - 1] : hy_prev_lane;
+            e.v[v] = e.v[v] + ((y.v[v] - left) - (x.v[v] - pvx.v[v])) * ce(v);
+        }
+    } else {
     VecN<T, V> dx, dy;
     dy.v[V - 1] = diff_next(e.v[0], e.v[V - 1]);                   // Ez[i, j+1] - Ez[i, j] across the lane edge
 #pragma unroll
@@ -71,6 +87,7 @@ __device__ __forceinline__ void staged_level(VecN<T, V> &e, VecN<T, V> &x, VecN<
 #pragma unroll
     for (int v = 0; v < V; ++v) e.v[v] = e.v[v] + dy.v[v];
     __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 // per-lane constants of a strip + the level update (same operations as stream_body)

@@ -135,21 +135,24 @@ __device__ __forceinline__ float diff_prev(float a, float b)
     asm volatile(DPP_PRE "v_subrev_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(b), "v"(a));
     return r;
 }
+// float64: no DPP form of the 64-bit arithmetic exists, a shift is two v_mov_b32_dpp; these stay with the
+// compiler (its own placement and hazard handling).  The hand-placed forms and the staged level body were
+// measured on float64 too: equal at 4096^2, 7 % faster at 8192^2, but 11-14 % SLOWER at 1024^2 / 2048^2 (8-step
+// passes, 54 vs 49 us), where float64 runs are likelier to live (profiles/r02_dpp_alignment.txt).
+__device__ __forceinline__ int dpp_next_c(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x130, 0xF, 0xF, true); }
+__device__ __forceinline__ int dpp_prev_c(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x138, 0xF, 0xF, true); }
 __device__ __forceinline__ double from_next(double x)
 {
     const long long b = __builtin_bit_cast(long long, x);
-    const unsigned lo = (unsigned)dpp_next((int)(unsigned)b), hi = (unsigned)dpp_next((int)(b >> 32));
+    const unsigned lo = (unsigned)dpp_next_c((int)(unsigned)b), hi = (unsigned)dpp_next_c((int)(b >> 32));
     return __builtin_bit_cast(double, (long long)(((unsigned long long)hi << 32) | lo));
 }
 __device__ __forceinline__ double from_prev(double x)
 {
     const long long b = __builtin_bit_cast(long long, x);
-    const unsigned lo = (unsigned)dpp_prev((int)(unsigned)b), hi = (unsigned)dpp_prev((int)(b >> 32));
+    const unsigned lo = (unsigned)dpp_prev_c((int)(unsigned)b), hi = (unsigned)dpp_prev_c((int)(b >> 32));
     return __builtin_bit_cast(double, (long long)(((unsigned long long)hi << 32) | lo));
 }
-
-__device__ __forceinline__ double diff_next(double a, double b) { return from_next(a) - b; }
-__device__ __forceinline__ double diff_prev(double a, double b) { return a - from_prev(b); }
 
 // One row of the strip on its way through the time levels: the registers of a slot are
 // loaded with level 0 of row r and then updated IN PLACE to level 1, 2, ... NT on the

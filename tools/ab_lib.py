@@ -14,6 +14,8 @@ import numpy as np
 sys.path.insert(0, %r)
 sys.path.insert(0, os.path.join(%r, "tools"))
 import fdtd2d_amd as fd
+from fdtd2d_amd import _abi
+if os.environ.get('AB_OLD_ABI'): _abi.SIGNATURES.pop('fdtd2d_rccl_selftest', None)
 import bench
 g, mat = int(sys.argv[1]), sys.argv[2]
 eng = bench.make_engine(fd, g, g, mat, 0, "mur")
@@ -25,7 +27,7 @@ print(json.dumps({"us": float(np.median(ms) * 1e3), "min": float(ms[0] * 1e3), "
 for g in grids:
     for r in range(rounds):
         for lib in libs:
-            env = dict(os.environ, FDTD2D_LIB=os.path.abspath(lib))
+            env = dict(os.environ, FDTD2D_LIB=os.path.abspath(lib), AB_OLD_ABI='1' if '/old/' in lib else '')
             p = subprocess.run([sys.executable, "-c", CHILD, str(g), mat], env=env, capture_output=True, text=True)
             line = [l for l in p.stdout.splitlines() if l.startswith("{")]
             print(g, mat, lib, line[-1] if line else ("FAILED " + p.stderr[-300:]), flush=True)

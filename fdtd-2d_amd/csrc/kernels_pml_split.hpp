@@ -177,10 +177,10 @@ __device__ __forceinline__ void split_body_pml(const PassParams<T> &p, const Pml
     typedef const char __attribute__((address_space(1))) *gcptr;
     auto row_ptr = [&](const T *field, int i) {
         gcptr rp = (gcptr)(field + at(g, i, 0));
-        asm volatile("" : "+s"(rp));
+        asm("" : "+s"(rp));
         return (const char *)rp;
     };
-    auto lane_off_now = [&]() { asm volatile("" : "+v"(lane_off)); return lane_off; };
+    auto lane_off_now = [&]() { asm("" : "+v"(lane_off)); return lane_off; };
     auto load_global = [&](Row &r, int i) {
         const int ic = min(max(i, row_lo), row_hi);
         const unsigned lo = lane_off_now();

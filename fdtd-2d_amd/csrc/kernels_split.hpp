@@ -241,16 +241,25 @@ __device__ __forceinline__ void split_body(const PassParams<T> &p, const int str
     // per-lane copy of the field pointer and adds the row offset with a 64-bit VALU add per access)
     // (it stays a GLOBAL pointer through the asm -- a generic one would turn the accesses into flat_load / flat_store)
     typedef const char __attribute__((address_space(1))) *gcptr;
+    // The byte offset of the row in hand is carried from tick to tick (the rows of a band come one after the
+    // other): the 64-bit row * pitch product is a chain of ten scalar instructions in front of every tick's
+    // loads, which small grids -- one or two waves per SIMD, ticks bound by latency -- paid with 8 %.
+    const long long pitch_b = (long long)g.pitch * (long long)sizeof(T);
+    int cur_row = ROLE == 2 ? ra : min(tau0, tau1 - 1);
+    long long cur_off = (long long)at(g, cur_row, 0) * (long long)sizeof(T);
     auto row_ptr = [&](const T *field, int i) {
-        gcptr rp = (gcptr)(field + at(g, i, 0));
-        asm volatile("" : "+s"(rp));
+        if (__builtin_expect(i == cur_row + 1, 1)) cur_off += pitch_b;            // the tick loop: the next row
+        else if (i != cur_row) cur_off = (long long)at(g, i, 0) * (long long)sizeof(T);
+        cur_row = i;
+        gcptr rp = (gcptr)(reinterpret_cast<const char *>(field) + cur_off);
+        asm("" : "+s"(rp));             // (not volatile: volatile statements keep their order among the DPP ones)
         return (const char *)rp;
     };
     // (and the lane offset through one as a vector register at each use: hoisted out of the loop as a 64-bit
     // value it is no longer the zero-extended 32-bit offset the scalar-base addressing form takes)
     // (in place, so that it keeps its own register: a copy lands in a register of the slot about to be loaded,
     // and the compiler then waits for that slot's previous load -- the whole prefetch -- before writing it)
-    auto lane_off_now = [&]() { asm volatile("" : "+v"(lane_off)); return lane_off; };
+    auto lane_off_now = [&]() { asm("" : "+v"(lane_off)); return lane_off; };
     auto load_global = [&](Row &r, int i) {
         const int ic = min(i, tau1 - 1);
         const unsigned lo = lane_off_now();
@@ -305,11 +314,13 @@ __device__ __forceinline__ void split_body(const PassParams<T> &p, const int str
             if (ROLE == 2) {
                 const int io = r - LV;
                 if (io >= ra && io < rb) {            // a row of the band (uniform) ...
+                    char *pe = const_cast<char *>(row_ptr(p.ez_out, io)), *px = const_cast<char *>(row_ptr(p.hx_out, io)),
+                         *py = const_cast<char *>(row_ptr(p.hy_out, io));
                     if (st_ok) {                      // ... and a column this strip owns (lanes masked off otherwise)
                         const unsigned lo = lane_off_now();
-                        stn<V>(reinterpret_cast<T *>(const_cast<char *>(row_ptr(p.ez_out, io)) + lo), f.e);
-                        stn<V>(reinterpret_cast<T *>(const_cast<char *>(row_ptr(p.hx_out, io)) + lo), f.x);
-                        stn<V>(reinterpret_cast<T *>(const_cast<char *>(row_ptr(p.hy_out, io)) + lo), f.y);
+                        stn<V>(reinterpret_cast<T *>(pe + lo), f.e);
+                        stn<V>(reinterpret_cast<T *>(px + lo), f.x);
+                        stn<V>(reinterpret_cast<T *>(py + lo), f.y);
                     }
                 }
             } else {

@@ -136,9 +136,10 @@ __device__ __forceinline__ float diff_prev(float a, float b)
     return r;
 }
 // float64: no DPP form of the 64-bit arithmetic exists, a shift is two v_mov_b32_dpp; these stay with the
-// compiler (its own placement and hazard handling).  The hand-placed forms and the staged level body were
-// measured on float64 too: equal at 4096^2, 7 % faster at 8192^2, but 11-14 % SLOWER at 1024^2 / 2048^2 (8-step
-// passes, 54 vs 49 us), where float64 runs are likelier to live (profiles/r02_dpp_alignment.txt).
+// compiler (its own placement and hazard handling) and the level keeps its chained form.  (A hand-placed run of
+// the two moves + the staged body measured equal at 4096^2 and 7 % faster at 8192^2; the 11-14 % it lost at
+// 1024^2 / 2048^2 in the same comparison turned out to be the `volatile` of the address laundering in
+// split_body, fixed since -- not re-measured for float64: profiles/r02_dpp_alignment.txt.)
 __device__ __forceinline__ int dpp_next_c(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x130, 0xF, 0xF, true); }
 __device__ __forceinline__ int dpp_prev_c(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x138, 0xF, 0xF, true); }
 __device__ __forceinline__ double from_next(double x)

@@ -45,7 +45,9 @@ template <bool CE_ARR> static int launch_pml_split(fdtd2d *h, fdtd::PassParams<f
     pp.band_rows_e = pp.band_rows;
     pp.nbands = (std::max(0, c_lo - a_hi) + pp.band_rows - 1) / pp.band_rows;
     const long long plain_blocks = (long long)pp.nbands * inner;
-    const bool both = layer_blocks > 0 && plain_blocks > 0;
+    // side by side on two streams where the piece is large; the 16-row pieces next to a slab's cuts run their two
+    // kernels one after the other on the handle's stream (a fork / join pair of events costs more than they take)
+    const bool both = layer_blocks > 0 && plain_blocks > 0 && region >= 256;
     if (both) {
         HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
         HIPCHK(h, hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));

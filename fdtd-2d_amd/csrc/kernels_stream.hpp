@@ -99,27 +99,18 @@ struct TraceScope {
 // ---- lane shifts -----------------------------------------------------------------------
 // from_next(x): lane l gets lane l+1's x; from_prev(x): lane l gets lane l-1's x.
 // (lane 63 / lane 0 get 0: those are strip-edge lanes whose results are never used)
-// A DPP-encoded instruction (8 bytes) that does not start on an 8-byte boundary stalls the SIMD's issue for
-// ~35 cycles once several waves share the SIMD (tools/ubench_dpp.hip, profiles/r02_ubench_dpp.txt: one DPP per
-// 16 plain VALU instructions = 110 ns per 64 instructions when misplaced, 73 ns on a boundary, 66 ns without;
-// VOP3-encoded plain instructions do not care).  The compiler places them wherever they fall -- in the pass
-// kernels every level had one of its two on the wrong phase -- so the lane shifts are written out with their
-// own alignment (the assembler pads with s_nop 0).  s_nop 1 = the two wait states a DPP read needs after a
-// VALU write of its source, which the compiler's hazard recogniser cannot see inside an asm statement.
-__device__ __forceinline__ int dpp_next(int x)
-{
-    int r;
-    asm volatile("s_nop 1\n\t.p2align 3\n\tv_mov_b32_dpp %0, %1 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(x));
-    return r;
-}
-__device__ __forceinline__ int dpp_prev(int x)
-{
-    int r;
-    asm volatile("s_nop 1\n\t.p2align 3\n\tv_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(x));
-    return r;
-}
-__device__ __forceinline__ float from_next(float x) { return __builtin_bit_cast(float, dpp_next(__builtin_bit_cast(int, x))); }
-__device__ __forceinline__ float from_prev(float x) { return __builtin_bit_cast(float, dpp_prev(__builtin_bit_cast(int, x))); }
+// A DPP-encoded instruction in the wrong place stalls the SIMD's issue once several waves share the SIMD
+// (tools/ubench_dpp.hip, ubench_align.hip; profiles/r02_ubench_dpp.txt, r02_ubench_align.txt: one DPP form per
+// 16-32 plain VALU instructions costs the SIMD 11-16 ns when it directly follows VALU work, 2-3 ns behind a few
+// s_nop or an alignment pad, nothing in a run of adjacent DPP forms).  In the level update of the pass kernels
+// (staged_level, kernels_split.hpp) the two lane shifts are therefore written out by hand at fixed places
+// (diff_next / diff_prev below): 6-8 % of a launch.  The generic shifts here -- Mur band of the edge strips,
+// k_bulk tails, PML layer body -- stay with the compiler (hand-written s_nop + aligned v_mov_b32_dpp forms
+// measured 0-2 % slower there, profiles/r02_dpp_alignment.txt).
+__device__ __forceinline__ int dpp_next_c(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x130, 0xF, 0xF, true); }
+__device__ __forceinline__ int dpp_prev_c(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x138, 0xF, 0xF, true); }
+__device__ __forceinline__ float from_next(float x) { return __builtin_bit_cast(float, dpp_next_c(__builtin_bit_cast(int, x))); }
+__device__ __forceinline__ float from_prev(float x) { return __builtin_bit_cast(float, dpp_prev_c(__builtin_bit_cast(int, x))); }
 // diff_next(a, b) = a of lane l+1  -  b;  diff_prev(a, b) = a  -  b of lane l-1  (one instruction each for float).
 // The CALLER keeps two instructions between a VALU write of the shifted operand and these (no s_nop inside).
 #define DPP_PRE ".p2align 3\n\t"
@@ -140,8 +131,6 @@ __device__ __forceinline__ float diff_prev(float a, float b)
 // the two moves + the staged body measured equal at 4096^2 and 7 % faster at 8192^2; the 11-14 % it lost at
 // 1024^2 / 2048^2 in the same comparison turned out to be the `volatile` of the address laundering in
 // split_body, fixed since -- not re-measured for float64: profiles/r02_dpp_alignment.txt.)
-__device__ __forceinline__ int dpp_next_c(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x130, 0xF, 0xF, true); }
-__device__ __forceinline__ int dpp_prev_c(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x138, 0xF, 0xF, true); }
 __device__ __forceinline__ double from_next(double x)
 {
     const long long b = __builtin_bit_cast(long long, x);

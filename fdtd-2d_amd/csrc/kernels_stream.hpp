@@ -127,10 +127,8 @@ __device__ __forceinline__ float diff_prev(float a, float b)
     return r;
 }
 // float64: no DPP form of the 64-bit arithmetic exists, a shift is two v_mov_b32_dpp; these stay with the
-// compiler (its own placement and hazard handling) and the level keeps its chained form.  (A hand-placed run of
-// the two moves + the staged body measured equal at 4096^2 and 7 % faster at 8192^2; the 11-14 % it lost at
-// 1024^2 / 2048^2 in the same comparison turned out to be the `volatile` of the address laundering in
-// split_body, fixed since -- not re-measured for float64: profiles/r02_dpp_alignment.txt.)
+// compiler (its own placement and hazard handling) and the level keeps its chained form: the staged body with a
+// hand-placed run of the two moves measured the same within 1 % from 512^2 to 8192^2 (profiles/r02_dpp_alignment.txt).
 __device__ __forceinline__ double from_next(double x)
 {
     const long long b = __builtin_bit_cast(long long, x);

@@ -1083,8 +1083,12 @@ static int tune_pass(fdtd2d *h, int nt, int lo, int hi, bool zt, bool zb, int sr
             fprintf(stderr, "tune nt=%d final %d: (%d, %d, %d) first rounds %.4f ms, now %.4f ms\n", nt, round,
                     cand[order[k]].band_rows, cand[order[k]].waves, cand[order[k]].edge_rows, best_of[order[k]], ms);
 #endif
-            if (ms < best_ms) {
-                best_ms = ms;
+            // (8 waves per strip run 5-7 % slower on a run's real fields than in these trials on the fields at
+            // hand -- zero in a fresh engine: 8192^2 ring map 0.53 ms in trials, 0.57 ms in the run, while the
+            // 4-wave shapes measure 0.52 both ways, profiles/r02_tuner_view.txt -- so they must win by that much)
+            const float score = cand[order[k]].waves == 8 ? ms * 1.06f : ms;
+            if (score < best_ms) {
+                best_ms = score;
                 best = cand[order[k]];
             }
         }

@@ -366,11 +366,16 @@ __device__ __forceinline__ void stream_body(const PassParams<T> &p, const int st
 
 // ---- the top/bottom zone tiles ---------------------------------------------------------------
 // One wave per tile: 32 columns x (2 NT + 6) rows of Ez (double-buffered), Hx, Hy in LDS.
-template <int NT> struct ZoneDims {
+template <int NT, bool WIDE = false> struct ZoneDims {
     static constexpr int ZO = 5 + NT;          // rows written per zone
     static constexpr int ZR = ZO + NT + 1;     // rows held in LDS
     static constexpr int M = NT + 1;           // margin columns per side
-    static constexpr int WL = NT <= 8 ? 32 : 64;   // columns held in LDS (a power of two >= 2 M + 8)
+    // columns held in LDS (a power of two >= 2 M + 8).  WIDE: the 20-step pass on wide grids -- its zones run as
+    // k_zone beside the bulk kernel, with LDS of their own: 128 columns (86 written of 128 held instead of 22 of 64;
+    // one 95 KB tile per CU leaves room for three bulk workgroups where three 48 KB tiles left room for none:
+    // run(20) 1738-1773 vs 1830-1866 us at 16384^2, 595 vs 621-630 at 8192^2 -- but 364 vs 239 at 4096^2, where the
+    // 96 long-lived tiles outlast the bulk: narrow tiles below 8192 columns, profiles/r02_nt20_small.txt)
+    static constexpr int WL = NT <= 8 ? 32 : (WIDE ? 128 : 64);
     static constexpr int WZ = WL - 2 * M;      // columns written per tile
     static constexpr int WLP = WL + 1;         // padded LDS row
     static constexpr int LDS_ELEMS = 4 * ZR * WLP;   // Ez (two buffers), Hx, Hy
@@ -401,11 +406,11 @@ template <class T, bool CE_ARR> struct TileAcc {
 
 // smem: ZoneDims<NT>::LDS_ELEMS elements of LDS owned by the calling kernel (k_bulk_split shares
 // the allocation with its hand-off buffers: a workgroup is either a zone tile or a strip)
-template <class T, int NT, bool CE_ARR, bool CH_ARR, int THREADS>
+template <class T, int NT, bool CE_ARR, bool CH_ARR, int THREADS, bool WIDE = false>
 __device__ __forceinline__ void zone_body(const PassParams<T> &p, const int tile, const bool bottom,
                                           T *smem)
 {
-    using D = ZoneDims<NT>;
+    using D = ZoneDims<NT, WIDE>;
     static_assert((D::WL & (D::WL - 1)) == 0 && THREADS % D::WL == 0 && D::WZ >= 8, "tile shape");
     // (offsets from the one LDS base, never a table of pointers: those become generic pointers and
     // flat loads; every tile index is clamped into the tile, see TileAcc::idx)
@@ -549,12 +554,18 @@ void k_bulk(const PassParams<T> p)
         stream_body<T, NT, CE_ARR, CH_ARR, false, V>(p, strip, ra, rb);
 }
 
-template <class T, int NT, bool CE_ARR, bool CH_ARR>
+template <class T, int NT, bool CE_ARR, bool CH_ARR, bool WIDE = false>
 __global__ __launch_bounds__(PASS_THREADS) void k_zone(const PassParams<T> p)
 {
-    __shared__ T smem[ZoneDims<NT>::LDS_ELEMS];
     const int z = blockIdx.x / p.zone_tiles;
-    zone_body<T, NT, CE_ARR, CH_ARR, PASS_THREADS>(p, blockIdx.x - z * p.zone_tiles, p.zone_top ? z == 1 : true, smem);
+    if constexpr (ZoneDims<NT, WIDE>::LDS_ELEMS * sizeof(T) > 65536) {      // beyond the static limit: dynamic LDS
+        extern __shared__ __attribute__((aligned(16))) unsigned char zone_dyn[];
+        zone_body<T, NT, CE_ARR, CH_ARR, PASS_THREADS, WIDE>(p, blockIdx.x - z * p.zone_tiles, p.zone_top ? z == 1 : true,
+                                                             reinterpret_cast<T *>(zone_dyn));
+    } else {
+        __shared__ T smem[ZoneDims<NT, WIDE>::LDS_ELEMS];
+        zone_body<T, NT, CE_ARR, CH_ARR, PASS_THREADS, WIDE>(p, blockIdx.x - z * p.zone_tiles, p.zone_top ? z == 1 : true, smem);
+    }
 }
 
 }  // namespace fdtd

@@ -52,8 +52,26 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
             if (side) {
                 HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
                 HIPCHK(h, hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
-                hipLaunchKernelGGL((fdtd::k_zone<T, NT, CE_ARR, CH_ARR>), dim3((unsigned)zones),
-                                   dim3(fdtd::PASS_THREADS), 0, h->side_stream, p);
+                bool wide = false;
+                if constexpr (NT > 16 && sizeof(T) == 4) {
+                    // 128-column tiles (dynamic LDS: 95 KB) on grids of 8192 columns and more, ZoneDims
+                    using DW = fdtd::ZoneDims<NT, true>;
+                    if (h->cols >= 8192) {
+                        wide = true;
+                        constexpr size_t zone_dyn = (size_t)DW::LDS_ELEMS * sizeof(T);
+                        // (every time: the attribute belongs to the device's code object, and a 20-step pass is a
+                        // millisecond-scale launch)
+                        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&fdtd::k_zone<T, NT, CE_ARR, CH_ARR, true>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)zone_dyn));
+                        p.zone_tiles = (h->cols + DW::WZ - 1) / DW::WZ;
+                        const long long wzones = (long long)(p.zone_top + p.zone_bot) * p.zone_tiles;
+                        hipLaunchKernelGGL((fdtd::k_zone<T, NT, CE_ARR, CH_ARR, true>), dim3((unsigned)wzones),
+                                           dim3(fdtd::PASS_THREADS), zone_dyn, h->side_stream, p);
+                    }
+                }
+                if (!wide)
+                    hipLaunchKernelGGL((fdtd::k_zone<T, NT, CE_ARR, CH_ARR>), dim3((unsigned)zones),
+                                       dim3(fdtd::PASS_THREADS), 0, h->side_stream, p);
                 HIPCHK(h, hipGetLastError());
                 HIPCHK(h, hipEventRecord(h->ev_join, h->side_stream));
             }

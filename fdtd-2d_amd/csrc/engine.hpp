@@ -23,6 +23,7 @@
 
 using fdtd::Geom;
 
+struct fdtd2d_slab;
 struct Range {
     int lo, hi;
 };
@@ -77,6 +78,7 @@ struct fdtd2d {
     void *scratch = nullptr;     // device scratch for snapshots / reduction partials
     size_t scratch_bytes = 0;
     std::string err;
+    struct fdtd2d_slab *slab = nullptr;   // state of the row-slab run loop (slab_loop.hip), owned by the handle
 #ifdef FDTD2D_TRACE
     void *trace_dev = nullptr;   // 4 x u64 per workgroup of the last level-split launch (profiling build)
     long long trace_blocks = 0;
@@ -157,8 +159,11 @@ struct fdtd2d {
         // fill/drain latency: measured faster from 4096^2 up, slower up to 3072^2
         // (profiles/r01_nt16_sweep.txt)
         const bool big = (size_t)nrows * cols >= (size_t)12 << 20;
+        // (PML: only when the 16-step pair can really run -- factor arrays set and equal to 1 outside the
+        // layer, uniform mu, no probe: callers use this figure as their exchange cycle and then ask
+        // fdtd2d_pass_rows for passes of exactly that length)
         if (max_nt >= 16 && (big || max_nt_forced) && dtype == FDTD2D_F32 && have_mat &&
-            (boundary == FDTD2D_BOUNDARY_MUR5 || (boundary == FDTD2D_BOUNDARY_PML && ch_uniform)))
+            (boundary == FDTD2D_BOUNDARY_MUR5 || (pml_split(16) && !probe_cap)))
             return 16;
         return std::min(max_nt, 8);
     }

@@ -39,13 +39,8 @@ struct fdtd2d_slab {
 
 namespace {
 
-std::map<fdtd2d *, fdtd2d_slab *> g_slabs;      // a handle's loop state (handles are not shared between threads)
-
-fdtd2d_slab *slab_of(fdtd2d *h)
-{
-    auto it = g_slabs.find(h);
-    return it == g_slabs.end() ? nullptr : it->second;
-}
+// the loop state lives in the handle (no global: distinct handles may be driven by distinct threads)
+fdtd2d_slab *slab_of(fdtd2d *h) { return h->slab; }
 
 // are the halo rows current (an exchange has happened since the last pass / upload)?
 bool halo_fresh(const fdtd2d *h)
@@ -89,7 +84,7 @@ int attach_common(fdtd2d *h, fdtd2d_slab *s)
         hipEventCreateWithFlags(&s->ev_main, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&s->ev_edge, hipEventDisableTiming) != hipSuccess)
         return fail(h, FDTD2D_E_NODEVICE, "stream / event creation for the slab loop failed");
-    g_slabs[h] = s;
+    h->slab = s;
     return 0;
 }
 
@@ -299,7 +294,7 @@ int fdtd2d_slab_detach(fdtd2d_t *h)
         for (void *p : {s->send[0], s->recv[0], s->send[1], s->recv[1]})
             if (p) (void)hipFree(p);
     if (s->comm && s->p_destroy) s->p_destroy(s->comm);
-    g_slabs.erase(h);
+    h->slab = nullptr;
     delete s;
     return 0;
 }
@@ -317,6 +312,17 @@ int fdtd2d_run_slab(fdtd2d_t *h, int nsteps, int cycle, int overlap, int src_row
     // interior is the caller's to establish before it passes overlap != 0): ranks that decided
     // differently would post their transfers in different orders.
     const bool can_overlap = overlap && h->rows >= 2 * (2 * cycle + 6) && (cycle == 8 || cycle == 16);
+    if (can_overlap) {
+        // two edge pieces of `halo` rows and an interior; on the first / last rank the interior piece must hold
+        // the whole top / bottom zone (5 + cycle rows with the Mur frame), which is written as a whole or not at
+        // all.  Checked before anything is posted: the caller passes overlap != 0 only when EVERY slab is at least
+        // 2 * halo + 5 rows tall (include/fdtd2d.h).
+        const int zo = h->boundary == FDTD2D_BOUNDARY_MUR5 ? 5 + cycle : 0;
+        const int need = std::max(2 * h->halo + 1, (h->top() || h->bottom()) ? h->halo + zo : 0);
+        if (h->nrows < need)
+            return fail(h, FDTD2D_E_ARG, "overlapped cycles need a slab of at least %d rows on this rank (it has %d): "
+                        "pass overlap = 0 on every rank", need, h->nrows);
+    }
     int done = 0, rc = 0;
     while (done < nsteps && !rc) {
         const int n = std::min(cycle, nsteps - done);

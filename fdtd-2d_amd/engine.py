@@ -123,14 +123,21 @@ class Engine:
                                                 _code(e.dtype), cptr, int(bool(allow_uniform))))
         return self
 
-    def set_pml(self, L=40, m=3, R0=1e-6, courant00=None):
+    def set_pml(self, L=40, m=3, R0=1e-6, courant00=None, profiles=None):
         """boundary="pml" only: build the split-field PML's factor arrays (pml_profiles) for
         the global grid and hand them to the engine.  courant00 = Courant number of the
-        [0,0] material cell (default: vacuum)."""
+        [0,0] material cell (default: vacuum).  profiles: the eight factor arrays themselves
+        (keys ahr bhr aer ber of length rows, ahc bhc aec bec of length cols) instead of the
+        graded ones; arrays that are not exactly 1 outside the L-cell layer run on the 8-step
+        kernel (cycle_steps says so)."""
         from .api import pml_profiles, EPS0, MU0
         if courant00 is None:
             courant00 = (1 / np.sqrt(EPS0 * MU0) * self.dt) / self.dx
-        P = pml_profiles(self.rows, self.cols, courant00, L, m, R0, self.dtype)
+        P = profiles if profiles is not None else pml_profiles(self.rows, self.cols, courant00, L, m, R0, self.dtype)
+        P = {k: np.asarray(P[k], dtype=self.dtype) for k in ("ahr", "bhr", "aer", "ber", "ahc", "bhc", "aec", "bec")}
+        if any(P[k].shape != (self.rows,) for k in ("ahr", "bhr", "aer", "ber")) or \
+                any(P[k].shape != (self.cols,) for k in ("ahc", "bhc", "aec", "bec")):
+            raise ValueError("PML factor arrays must have length rows (..r) / cols (..c)")
         rowf = np.ascontiguousarray(np.concatenate([P["ahr"], P["bhr"], P["aer"], P["ber"]]))
         colf = np.ascontiguousarray(np.concatenate([P["ahc"], P["bhc"], P["aec"], P["bec"]]))
         self._ck(self._lib.fdtd2d_set_pml(self._h, rowf.ctypes.data, colf.ctypes.data, _code(self.dtype),

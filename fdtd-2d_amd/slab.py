@@ -106,7 +106,9 @@ class SlabRunner:
         # orders and deadlock.
         self.boundary = boundary
         self.min_slab = min(b - a for a, b in self.plan)
-        self.overlap = bool(overlap) and self.world > 1 and self.min_slab >= 2 * self.halo + 1 and \
+        # (2 * halo + 5: two edge pieces of `halo` rows, and on the first / last rank an interior piece
+        # that holds the whole 5 + cycle rows of the top / bottom zone -- a piece may not cut through it)
+        self.overlap = bool(overlap) and self.world > 1 and self.min_slab >= 2 * self.halo + 5 and \
             hasattr(self.engine, "pass_rows")
         self.cycle = None            # steps per exchange, agreed in set_materials()
         self._halo_fresh = False
@@ -364,6 +366,11 @@ class SlabRunner:
         """Ez[row, col] after every step of the following run() calls; recorded on the rank that
         owns the row (read it there with read_probe)."""
         self._probe_owner = self.r0 <= int(row) < self.r1
+        if self.boundary == "pml" and self.world > 1:
+            # the PML passes have no probe tile: the owner advances by single steps, and a rank that runs
+            # plain cycles while its neighbours run overlapped ones would post its transfers in another
+            # order -- every rank calls set_probe, so every rank drops the overlap here
+            self.overlap = False
         if self._probe_owner or self.world == 1:
             self.engine.set_probe(row, col, capacity)
         return self

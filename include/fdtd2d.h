@@ -275,7 +275,12 @@ int fdtd2d_halo_unpack(fdtd2d_t *h, int side, const void *dev_buf);
  * hipStream_t) -- or complete before returning -- the transfer of this rank's packed send buffers to
  * the neighbours' recv buffers (NULL pointers: no neighbour on that side); return 0 on success.
  * Every rank must pass the same nsteps, cycle (<= halo; what all ranks' fdtd2d_info(CYCLE_STEPS)
- * agree on) and overlap flag: ranks that disagree post their transfers in different orders. */
+ * agree on) and overlap flag: ranks that disagree post their transfers in different orders.
+ * overlap != 0 needs EVERY slab to be at least 2 * halo + 5 rows tall (two edge pieces of `halo` rows and an
+ * interior that holds the whole top / bottom zone on the first / last rank); a rank whose slab is shorter
+ * returns FDTD2D_E_ARG before it posts anything.  With the PML and a probe set no temporally blocked pass
+ * exists (fdtd2d_info(CYCLE_STEPS) says 8, passes fail): run such handles with overlap = 0 on every rank.
+ * The loop state belongs to the handle (no global table): distinct handles may run on distinct threads. */
 typedef int (*fdtd2d_exchange_fn)(void *ctx, void *send_top, void *recv_top, void *send_bottom,
                                   void *recv_bottom, long long bytes, void *stream);
 int fdtd2d_slab_attach(fdtd2d_t *h, void *send_top, void *recv_top, void *send_bottom, void *recv_bottom,

@@ -36,6 +36,11 @@ DT, DX = 5e-14, 1e-4
     # first overlapped cycle, after the rows next to the cuts have been issued
     (2, (2400, 3600), "float32", "uniform", True, {"max_pass_steps": 16, "loop": "c"}),
     (2, (2400, 3600), "float32", "uniform", True, {"max_pass_steps": 16}),
+    # slabs of 35 / 36 rows with forced 16-step cycles: an edge piece would cut through the 21-row top / bottom zone
+    # of the first / last rank, so every rank must run plain cycles (round-2 advisor finding)
+    (3, (105, 300), "float32", "uniform", True, {"max_pass_steps": 16, "loop": "c", "expect_overlap": False}),
+    (3, (108, 300), "float32", "array", True, {"max_pass_steps": 16, "expect_overlap": False}),
+    (3, (111, 300), "float32", "uniform", True, {"max_pass_steps": 16, "loop": "c", "expect_overlap": True}),
 ])
 def test_gpu_slabs_match_single_engine_and_oracle(tmp_path, world, shape, dtype, materials, overlap,
                                                   options):
@@ -44,6 +49,7 @@ def test_gpu_slabs_match_single_engine_and_oracle(tmp_path, world, shape, dtype,
     r, c = shape
     options = dict(options or {})
     loop = options.pop("loop", "python")
+    expect_overlap = options.pop("expect_overlap", None)
     n = 45 if options else 29                # exchange cycles 8+8+8+5 (passes 8,8,8,4,1) / 16+16+13
     rng = np.random.default_rng(r + c)
     st = dict(Ez=rng.standard_normal((r, c)), Hx=rng.standard_normal((r, c - 1)) * 1e-3,
@@ -59,7 +65,7 @@ def test_gpu_slabs_match_single_engine_and_oracle(tmp_path, world, shape, dtype,
     job = dict(engine="hip", shape=shape, dtype=dtype, dt=DT, dx=DX, state=path, src=src,
                chunks=[n], materials=materials, overlap=overlap, loop=loop,
                options={k: v for k, v in (options or {}).items() if k != "extent"} or None,
-               extent=(options or {}).get("extent"))
+               extent=(options or {}).get("extent"), expect_overlap=expect_overlap)
     got = run_job(world, job, str(tmp_path))
     dt_ = np.dtype(dtype)
     with fd.Engine(r, c, DT, DX, dtype=dt_) as eng:
@@ -157,3 +163,126 @@ def test_rccl_transport_glue_on_one_gpu(with_torch):
     assert p.returncode == 0 and "RCCL_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("RCCL_OK")][-1]
     assert line.count("librccl") == 1, "two RCCL builds in one process: " + line
+
+
+# ---- 8 ranks: BASELINE configs[3] / configs[4]'s decomposition, one thread per rank (tests/local_slabs.py) -------
+
+def _slab_state(r, c, n, seed, eps_hi=10.0, zero_fields=False):
+    from oracle import fdtd_numpy as onp
+    rng = np.random.default_rng(seed)
+    st = dict(Ez=rng.standard_normal((r, c)), Hx=rng.standard_normal((r, c - 1)) * 1e-3,
+              Hy=rng.standard_normal((r - 1, c)) * 1e-3,
+              eps=onp.EPS0 * rng.uniform(1, eps_hi, (r, c)), mu=onp.MU0 * np.ones((r, c)),
+              amps=rng.standard_normal(n), dt=DT, dx=DX)
+    if zero_fields:
+        for k in ("Ez", "Hx", "Hy"):
+            st[k][:] = 0
+    st["eps"][0, 0] = onp.EPS0
+    return st
+
+
+@pytest.mark.parametrize("world,shape,cycle_opt,materials,n", [
+    (8, (8 * 48, 520), 16, "uniform", 45),     # overlapped 16-step cycles, 16 + 16 + 13
+    (8, (8 * 40, 300), None, "array", 29),     # small slabs: 8-step cycles
+    (5, (5 * 37, 700), 16, "array", 35),       # the shortest slabs that still overlap with 16-step cycles
+])
+def test_eight_mur_slabs_in_one_process_match_single_engine_and_oracle(world, shape, cycle_opt, materials, n):
+    import fdtd2d_amd as fd
+    from oracle import fdtd_numpy as onp
+    from local_slabs import run_local_slabs
+    r, c = shape
+    st = _slab_state(r, c, n, r + c)
+    if materials == "uniform":
+        st["eps"][:] = 2.5 * onp.EPS0
+    src = (r // world, c // 2)
+    got, cycle, overlapped, launches = run_local_slabs(fd, world, shape, np.float32, "mur", st, n, src,
+                                                       cycle_opt=cycle_opt, materials=materials)
+    assert cycle == (16 if cycle_opt else 8) and overlapped and min(launches) > 0
+    ref = [st[k].astype(np.float32) for k in ("Ez", "Hx", "Hy")]
+    onp.leapfrog(*ref, st["eps"].astype(np.float32), st["mu"].astype(np.float32), DT, DX, n, src[0], src[1],
+                 amps=st["amps"])
+    for a, b, k in zip(got, ref, ("Ez", "Hx", "Hy")):
+        assert np.array_equal(a, b), f"{k}: {world} slabs differ from the oracle at {np.argwhere(a != b)[:3]}"
+
+
+@pytest.mark.parametrize("cycle_opt,n,overlap", [(16, 45, True), (16, 37, False), (None, 21, True)])
+def test_eight_pml_slabs_in_one_process_match_single_engine_and_oracle(cycle_opt, n, overlap):
+    """BASELINE configs[4]'s decomposition -- 8 row slabs, boundary="pml", float32 -- on a small grid: ranks 0 and 7
+    hold the top / bottom layer, every rank the two column layers; 4-field halo messages, overlapped 16-step cycles
+    on the level-split pair (k_bulk_split + k_bulk_split_pml), the run loop in C.  Equal to the single engine and
+    to the build's PML oracle (parity unpinned: no time-domain PML in the reference) bit for bit."""
+    import fdtd2d_amd as fd
+    from oracle import pml_numpy as pm
+    from local_slabs import run_local_slabs
+    world, r, c = 8, 8 * 64, 600
+    st = _slab_state(r, c, n, 77 + n, eps_hi=3.0, zero_fields=True)
+    src = (2 * 64, 301)                                  # on a cut
+    got, cycle, overlapped, launches = run_local_slabs(fd, world, (r, c), np.float32, "pml", st, n, src,
+                                                       cycle_opt=cycle_opt, overlap=overlap)
+    assert cycle == (16 if cycle_opt else 8) and overlapped == overlap and min(launches) > 0
+    eps, mu = st["eps"].astype(np.float32), st["mu"].astype(np.float32)
+    with fd.Engine(r, c, DT, DX, dtype=np.float32, boundary="pml") as eng:
+        eng.set_materials(eps, mu).set_pml()
+        if cycle_opt:
+            eng.set_option(max_pass_steps=cycle_opt)
+        eng.run(n, src[0], src[1], st["amps"])
+        one = eng.download()
+    S = (1 / np.sqrt(fd.EPS0 * fd.MU0) * DT) / DX
+    ref = [np.zeros((r, c), np.float32), np.zeros((r, c), np.float32), np.zeros((r, c - 1), np.float32),
+           np.zeros((r - 1, c), np.float32)]
+    pm.leapfrog(*ref, eps, mu, DT, DX, n, src[0], src[1], st["amps"], pm.profiles(r, c, S, dtype=np.float32))
+    assert np.abs(one[0]).max() > 0
+    for a, b, c_, k in zip(got, one, (ref[0], ref[2], ref[3]), ("Ez", "Hx", "Hy")):
+        assert np.array_equal(a, b), f"{k}: 8 slabs differ from the single engine at {np.argwhere(a != b)[:3]}"
+        assert np.array_equal(a, c_), f"{k}: 8 slabs differ from the PML oracle at {np.argwhere(a != c_)[:3]}"
+
+
+def test_pml_factor_arrays_without_unit_structure_keep_the_8_step_cycle():
+    """Round-2 advisor finding: cycle_steps() said 16 for every float32 PML handle with uniform mu, also when the
+    factor arrays are not 1 outside the layer -- then only the 8-step kernel can run them, and a slab loop that
+    took 16 as its exchange cycle failed mid-run.  Now the handle reports 8, the slabs cycle by 8 and the result
+    equals the single engine and the oracle run with the same arrays."""
+    import fdtd2d_amd as fd
+    from oracle import pml_numpy as pm
+    from local_slabs import run_local_slabs
+    world, r, c, n = 3, 3 * 70, 300, 27
+    st = _slab_state(r, c, n, 5, eps_hi=3.0, zero_fields=True)
+    S = (1 / np.sqrt(fd.EPS0 * fd.MU0) * DT) / DX
+    P = pm.profiles(r, c, S, dtype=np.float32)
+    P["ahr"] = P["ahr"].copy()
+    P["ahr"][r // 2] = np.float32(0.97)                  # an H factor != 1 outside the layer
+    src = (70, 150)
+    got, cycle, overlapped, _ = run_local_slabs(fd, world, (r, c), np.float32, "pml", st, n, src, cycle_opt=16,
+                                                pml=dict(profiles=P))
+    assert cycle == 8 and overlapped
+    eps, mu = st["eps"].astype(np.float32), st["mu"].astype(np.float32)
+    with fd.Engine(r, c, DT, DX, dtype=np.float32, boundary="pml") as eng:
+        eng.set_materials(eps, mu).set_pml(profiles=P).set_option(max_pass_steps=16)
+        assert eng.cycle_steps == 8
+        eng.run(n, src[0], src[1], st["amps"])
+        one = eng.download()
+        assert eng.info(16) > 0
+    ref = [np.zeros((r, c), np.float32), np.zeros((r, c), np.float32), np.zeros((r, c - 1), np.float32),
+           np.zeros((r - 1, c), np.float32)]
+    pm.leapfrog(*ref, eps, mu, DT, DX, n, src[0], src[1], st["amps"], P)
+    for a, b, c_, k in zip(got, one, (ref[0], ref[2], ref[3]), ("Ez", "Hx", "Hy")):
+        assert np.array_equal(a, b), f"{k}: slabs differ from the single engine"
+        assert np.array_equal(a, c_), f"{k}: slabs differ from the PML oracle"
+
+
+def test_c_loop_refuses_overlap_on_slabs_that_cut_the_zone():
+    """fdtd2d_run_slab(overlap=1) on 35-row slabs with 16-step cycles: the first / last rank returns FDTD2D_E_ARG
+    before it posts anything (its edge piece would cut through the 21-row zone)."""
+    import fdtd2d_amd as fd
+    from fdtd2d_amd import _abi
+    r, c = 105, 300
+    with fd.Engine(r, c, DT, DX, dtype=np.float32, slab=(0, 35, 16)) as eng:
+        eng.set_materials().set_option(max_pass_steps=16)
+        import torch
+        n = eng.halo_bytes // 4
+        send, recv = torch.zeros(n, device="cuda:0"), torch.zeros(n, device="cuda:0")
+        called = []
+        eng.slab_attach({1: (send.data_ptr(), recv.data_ptr())}, lambda *a: called.append(a) or 0)
+        with pytest.raises(_abi.Fdtd2dError) as e:
+            eng.run_slab(16, 16, True)
+        assert e.value.code == _abi.E_ARG and not called

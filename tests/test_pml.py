@@ -169,3 +169,97 @@ def test_device_pml_passes_match_oracle(dtype, shape, L, arrays):
     for out, what in zip(outs, ("16-step passes", "8-step passes", "step kernels")):
         for a, b, k in zip(out, ref, ("Ez", "Ezx", "Hx", "Hy")):
             assert np.array_equal(a, b), f"{k}: {what} vs oracle {np.argwhere(a != b)[:4]}"
+
+
+# ---- BASELINE configs[4] at full size: one rank's 4096 x 32768 slab ---------------------------------------------
+
+def _pml_three_ways(make_engine, fill, n=16):
+    """The same n steps on the 16-step level-split pair, the 8-step kernel and the single-step kernels (the last is
+    the one checked against the PML oracle cell for cell at small sizes); returns [(Ez, Ezx, Hx, Hy)] x 3."""
+    outs = []
+    for max_nt in (16, 8, 0):
+        eng = make_engine()
+        try:
+            eng.set_option(max_pass_steps=max_nt)
+            fill(eng)
+            eng.run(n)
+            got = eng.download()
+            gx = eng.download_ezx()
+            assert (eng.info(16) > 0) == (max_nt > 0)
+            if max_nt:
+                assert eng.cycle_steps == max_nt
+        finally:
+            eng.close()
+        outs.append((got[0], gx, got[1], got[2]))
+    return outs
+
+
+@pytest.mark.gpu
+def test_full_size_pml_slab_whole_grid_4096x32768():
+    """The workload bench.py times as "one rank of configs[4]" (4096 x 32768 fp32, uniform, 40-cell layer on all
+    four sides), from a random state, 32 steps: 16-step pair == 8-step passes == single-step kernels on every cell,
+    and Ezx stays exactly 0 outside the layer (there the reference's update is the whole story)."""
+    import fdtd2d_amd as fd
+    r, c, L = 4096, 32768, 40
+    rng = np.random.default_rng(4096)
+    init = [rng.standard_normal((r, c), dtype=np.float32),
+            rng.standard_normal((r, c - 1), dtype=np.float32) * np.float32(1e-3),
+            rng.standard_normal((r - 1, c), dtype=np.float32) * np.float32(1e-3)]
+
+    def make():
+        return fd.Engine(r, c, DT, DX, dtype=np.float32, boundary="pml").set_materials().set_pml(L=L)
+
+    outs = _pml_three_ways(make, lambda eng: eng.upload(*init), n=32)
+    for other, what in ((outs[1], "8-step passes"), (outs[2], "single steps")):
+        for a, b, k in zip(outs[0], other, ("Ez", "Ezx", "Hx", "Hy")):
+            assert np.array_equal(a, b), f"{k}: 16-step pair vs {what} at {np.argwhere(a != b)[:3]}"
+    Ezx = outs[0][1]
+    assert not Ezx[L:r - L, L:c - L].any() and Ezx[:L].any() and Ezx[:, :L].any() and Ezx[:, c - L:].any()
+    assert np.isfinite(outs[0][0]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rank", [0, 3, 7])
+def test_full_size_pml_slab_of_config5(rank):
+    """Rank `rank` of BASELINE configs[4] itself: rows [4096 rank, 4096 (rank + 1)) of the 32768 x 32768 grid with
+    16 halo rows, array eps; halos filled from a random message (what a neighbour would send), 16 steps: the
+    16-step pair == 8-step passes + ... == single-step kernels on every owned cell.  Rank 0 / 7 own the top /
+    bottom layer, rank 3 only the column layers."""
+    import torch
+    import fdtd2d_amd as fd
+    R = C = 32768
+    r0, nr, halo, L = 4096 * rank, 4096, 16, 40
+    rng = np.random.default_rng(rank)
+    lo, hi = max(0, r0 - halo), min(R, r0 + nr + halo)
+    eps = (fd.EPS0 * (1 + 2 * rng.random((hi - lo, C), dtype=np.float32))).astype(np.float32)
+    mu = np.full((hi - lo, C), fd.MU0, np.float32)
+    nhy = nr if rank < 7 else nr - 1
+    init = [rng.standard_normal((nr, C), dtype=np.float32),
+            rng.standard_normal((nr, C - 1), dtype=np.float32) * np.float32(1e-3),
+            rng.standard_normal((nhy, C), dtype=np.float32) * np.float32(1e-3)]
+    # a message as a neighbour's fdtd2d_halo_pack lays it out: [Ez, Ezx, Hx, Hy][halo rows][C]; Ezx is zero outside
+    # the column layers and Hx's column C-1 does not exist (permanent zero), as in any state the engine produces
+    m = rng.standard_normal((4, halo, C), dtype=np.float32) * np.float32(1e-3)
+    m[1, :, L:C - L] = 0
+    m[2, :, C - 1] = 0
+    msg = torch.from_numpy(m.reshape(-1)).to("cuda:0")
+
+    def make():
+        eng = fd.Engine(R, C, DT, DX, dtype=np.float32, boundary="pml", slab=(r0, nr, halo))
+        return eng.set_materials(eps, mu, corner=(fd.EPS0, fd.MU0)).set_pml(L=L)
+
+    def fill(eng):
+        eng.upload(*init)
+        for side in (0, 1):
+            if (side == 0 and rank > 0) or (side == 1 and rank < 7):
+                eng.halo_unpack(side, msg.data_ptr())
+        eng.sync()
+
+    outs = _pml_three_ways(make, fill, n=16)
+    for other, what in ((outs[1], "8-step passes"), (outs[2], "single steps")):
+        for a, b, k in zip(outs[0], other, ("Ez", "Ezx", "Hx", "Hy")):
+            assert np.array_equal(a, b), f"{k}: rank {rank}, 16-step pair vs {what} at {np.argwhere(a != b)[:3]}"
+    Ezx = outs[0][1]
+    top = L if rank == 0 else 0
+    bot = nr - L if rank == 7 else nr
+    assert not Ezx[top:bot, L:C - L].any() and Ezx[:, :L].any()

@@ -2,7 +2,7 @@
 skunnavakkam/fdtd-2d (python-src/main.py update_Hx_Hy / update_Ez / ricker as looped by
 python-src/fdtd.py).  Import it as ``fdtd2d_amd`` (a directory name with '-' is not an
 identifier; ``fdtd2d_amd/__init__.py`` at the repo root points here)."""
-from ._abi import Fdtd2dError, LIB_PATH  # noqa: F401
+from ._abi import ARITHMETIC, Fdtd2dError, LIB_PATH  # noqa: F401
 from .api import (EPS0, MU0, capture_snapshot, courant_number, grid_init, invalidate_cache, material_init,  # noqa: F401
                   pml_profiles, render_snapshot, ricker, ricker_amplitude, run_fdtd, sinusoidal,
                   sinusoidal_amplitude, snapshot_indices, eps_background, step, update_Ez,

@@ -10,22 +10,29 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+# FDTD2D_ARITHMETIC=fused selects the tolerance build (libfdtd2d_fused.so: multiply-add pairs contracted into FMA,
+# results within rounding of the reference's); default "exact" = value-identical to the reference.
 # FDTD2D_LIB: alternative build of the same library (kernel A/B experiments only)
-LIB_PATH = os.environ.get("FDTD2D_LIB") or os.path.join(HERE, "libfdtd2d.so")
+ARITHMETIC = os.environ.get("FDTD2D_ARITHMETIC", "exact")
+if ARITHMETIC not in ("exact", "fused"):
+    raise ImportError(f"FDTD2D_ARITHMETIC must be 'exact' or 'fused', not {ARITHMETIC!r}")
+LIB_PATH = os.environ.get("FDTD2D_LIB") or os.path.join(
+    HERE, "libfdtd2d.so" if ARITHMETIC == "exact" else "libfdtd2d_fused.so")
 
 F32, F64 = 0, 1
 BOUNDARY_NONE, BOUNDARY_MUR5, BOUNDARY_PML = 0, 1, 2
 SRC_NONE, SRC_RICKER, SRC_SINUSOIDAL = 0, 1, 2
 FIELD_EZ, FIELD_HX, FIELD_HY = 0, 1, 2
 
-OPT_MAX_PASS_STEPS, OPT_BAND_ROWS, OPT_ZONE_SPLIT, OPT_LEVEL_SPLIT, OPT_SPLIT_WAVES, OPT_AUTOTUNE, OPT_LONG_SHAPE = 0, 1, 2, 3, 4, 5, 6
+OPT_MAX_PASS_STEPS, OPT_BAND_ROWS, OPT_ZONE_SPLIT, OPT_LEVEL_SPLIT, OPT_SPLIT_WAVES, OPT_AUTOTUNE, OPT_LONG_SHAPE, OPT_XCD_MAP = 0, 1, 2, 3, 4, 5, 6, 7
 
 E_ARG, E_NODEVICE, E_NOMEM, E_STATE, E_COURANT = -1, -2, -3, -4, -5
 
 (INFO_ROWS, INFO_COLS, INFO_ROW0, INFO_NROWS, INFO_HALO, INFO_PITCH, INFO_DTYPE,
  INFO_BOUNDARY, INFO_DEVICE, INFO_EPS_UNIFORM, INFO_MU_UNIFORM, INFO_E_VALID_LO,
  INFO_E_VALID_HI, INFO_H_VALID_LO, INFO_H_VALID_HI, INFO_STEP, INFO_PASS_LAUNCHES,
- INFO_STEP_LAUNCHES, INFO_CYCLE_STEPS, INFO_LAST_BAND_ROWS, INFO_LAST_WAVES, INFO_LAST_EDGE_ROWS) = range(22)
+ INFO_STEP_LAUNCHES, INFO_CYCLE_STEPS, INFO_LAST_BAND_ROWS, INFO_LAST_WAVES, INFO_LAST_EDGE_ROWS,
+ INFO_LAST_PASS_STEPS) = range(23)
 
 _vp, _i, _d, _ll = C.c_void_p, C.c_int, C.c_double, C.c_longlong
 
@@ -68,12 +75,15 @@ SIGNATURES = {
     "fdtd2d_rccl_selftest": (_i, [_i, _ll]),
     "fdtd2d_slab_attach_rccl": (_i, [_vp, _vp, _i, _i]),
     "fdtd2d_slab_detach": (_i, [_vp]),
+    "fdtd2d_slab_ranks": (_ll, [_vp]),
     "fdtd2d_run_slab": (_i, [_vp, _i, _i, _i, _i, _i, C.POINTER(_d)]),
     "fdtd2d_snapshot_index": (_i, [_vp, _d, _d, _i, _vp]),
     "fdtd2d_reduce": (_i, [_vp, _i, C.POINTER(_d), C.POINTER(_d)]),
     "fdtd2d_timer_start": (_i, [_vp]),
     "fdtd2d_timer_stop": (_i, [_vp, C.POINTER(C.c_float)]),
     "fdtd2d_time_launches": (_i, [_vp, _i, _i, C.POINTER(C.c_float)]),
+    "fdtd2d_clock_probe_start": (_i, [_vp, _i]),
+    "fdtd2d_clock_probe_read": (_i, [_vp, C.POINTER(_d)]),
     "fdtd2d_bytes_per_cell_step": (_i, [_vp]),
     "fdtd2d_device_ptr": (_vp, [_vp, _i]),
     "fdtd2d_version": (C.c_char_p, []),

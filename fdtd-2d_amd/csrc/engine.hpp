@@ -135,10 +135,18 @@ struct fdtd2d {
     };
     std::map<std::array<int, 3>, Shape> tuned;
     int autotune = 1;            // FDTD2D_OPT_AUTOTUNE
-    Shape long_shape{0, 0};      // FDTD2D_OPT_LONG_SHAPE: shape of full-length passes given by the caller
-                                 // (a shape measured elsewhere, e.g. by another process)
+    // FDTD2D_OPT_LONG_SHAPE: launch shapes given by the caller (measured elsewhere, e.g. by another process), by
+    // pass length; key 0 = the full-length passes (cycle_steps())
+    std::map<int, Shape> given_shape;
+    const Shape *shape_given(int nt) const
+    {
+        auto it = given_shape.find(nt);
+        if (it == given_shape.end() && nt == cycle_steps()) it = given_shape.find(0);
+        return it != given_shape.end() && it->second.band_rows > 0 ? &it->second : nullptr;
+    }
     Shape shape_now{0, 0};       // shape of the launch being issued (set by launch_pass)
     Shape shape_last{0, 0};      // band height / waves per strip actually used by the last pass
+    int last_nt = 0;             // its kernel length
     int split_waves = 0;         // waves per strip in k_bulk_split: 0 = automatic, 4 or 8
     int split_waves_for(int nt, int lo, int hi) const
     {
@@ -167,6 +175,9 @@ struct fdtd2d {
             return 16;
         return std::min(max_nt, 8);
     }
+    int xcd_map = 0;             // FDTD2D_OPT_XCD_MAP
+    unsigned long long *clk_dev = nullptr;   // clock probe stamps (fdtd2d_clock_probe_*)
+    hipStream_t clk_stream = nullptr;
     int zone_split = -1;         // -1: by launch size; 0/1: force fused / side-stream zones (FDTD2D_OPT_ZONE_SPLIT)
     int max_nt = 20;             // longest pass; FDTD2D_OPT_MAX_PASS_STEPS (0: step kernels only)
 };

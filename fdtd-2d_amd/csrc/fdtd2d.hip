@@ -602,7 +602,14 @@ template <class T, bool PACK> int launch_halo(fdtd2d *h, int first, void *buf)
 
 extern "C" {
 
-const char *fdtd2d_version(void) { return "fdtd2d-mi355x 0.1 (gfx950)"; }
+const char *fdtd2d_version(void)
+{
+#ifdef FDTD2D_FUSED
+    return "fdtd2d-mi355x 0.3 (gfx950, fused multiply-add: tolerance build)";
+#else
+    return "fdtd2d-mi355x 0.3 (gfx950, one rounding per operation: value-identical build)";
+#endif
+}
 
 int fdtd2d_create(fdtd2d_t **out, int rows, int cols, double dt, double dx, int dtype,
                   int boundary, int device)
@@ -629,6 +636,8 @@ void fdtd2d_destroy(fdtd2d_t *h)
         if (h->scratch) (void)hipFree(h->scratch);
         if (h->trash) (void)hipFree(h->trash);
         if (h->probe_dev) (void)hipFree(h->probe_dev);
+        if (h->clk_dev) (void)hipFree(h->clk_dev);
+        if (h->clk_stream) { (void)hipStreamSynchronize(h->clk_stream); (void)hipStreamDestroy(h->clk_stream); }
         if (h->side_stream) { (void)hipStreamSynchronize(h->side_stream); (void)hipStreamDestroy(h->side_stream); }
         if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
         if (h->ev_join) (void)hipEventDestroy(h->ev_join);
@@ -667,6 +676,7 @@ long long fdtd2d_info(const fdtd2d_t *h, int what)
     case FDTD2D_INFO_LAST_BAND_ROWS: return h->shape_last.band_rows;
     case FDTD2D_INFO_LAST_WAVES: return h->shape_last.waves;
     case FDTD2D_INFO_LAST_EDGE_ROWS: return h->shape_last.edge_rows;
+    case FDTD2D_INFO_LAST_PASS_STEPS: return h->last_nt;
     default: return FDTD2D_E_ARG;
     }
 }
@@ -939,7 +949,7 @@ static int tune_pass(fdtd2d *h, int nt, int lo, int hi, bool zt, bool zb, int sr
     const std::array<int, 3> key{nt, lo, hi};
     if (!h->autotune || h->stream_band_rows > 0 || nt < 8 ||
         (h->boundary != FDTD2D_BOUNDARY_MUR5 && !h->pml_split(nt)) ||
-        (h->long_shape.band_rows > 0 && nt == h->cycle_steps()) ||
+        h->shape_given(nt) ||
         (size_t)std::max(0, hi - lo) * h->cols < ((size_t)4 << 20) || h->tuned.count(key))
         return 0;
     std::vector<fdtd2d::Shape> cand{{0, 0}};
@@ -1310,11 +1320,17 @@ int fdtd2d_set_option(fdtd2d_t *h, int option, long long value)
         h->zone_split = (int)value;
         h->tuned.clear();
         return 0;
+    case FDTD2D_OPT_XCD_MAP:
+        if (value != 0 && value != 1) return fail(h, FDTD2D_E_ARG, "xcd map must be 0 or 1");
+        h->xcd_map = (int)value;
+        h->tuned.clear();
+        return 0;
     case FDTD2D_OPT_LONG_SHAPE: {
         const int br = (int)(value & 0xffff), nw = (int)((value >> 16) & 0xffff), er = (int)((value >> 32) & 0xffff);
-        if (value < 0 || (nw != 0 && nw != 4 && nw != 8))
-            return fail(h, FDTD2D_E_ARG, "shape = band rows + 65536 * waves (0, 4 or 8) + 2^32 * edge band rows");
-        h->long_shape = fdtd2d::Shape{br, nw, er};
+        const int nt = (int)((value >> 48) & 0xff);       // 0: the full-length passes
+        if (value < 0 || (nw != 0 && nw != 4 && nw != 8) || nt > fdtd::STREAM_MAX_NT)
+            return fail(h, FDTD2D_E_ARG, "shape = band rows + 2^16 * waves (0, 4 or 8) + 2^32 * edge band rows + 2^48 * pass length");
+        h->given_shape[nt] = fdtd2d::Shape{br, nw, er};
         return 0;
     }
     default: return fail(h, FDTD2D_E_ARG, "unknown option %d", option);
@@ -1495,6 +1511,61 @@ int fdtd2d_time_launches(fdtd2d_t *h, int nlaunch, int steps_each, float *ms)
         if (hipEventElapsedTime(&ms[n], ev[2 * n], ev[2 * n + 1]) != hipSuccess) rc = fail(h, FDTD2D_E_STATE, "hipEventElapsedTime failed");
     cleanup();
     return rc;
+}
+
+namespace {
+constexpr int CLK_PROBES = 16;
+// one wave per workgroup: sleeps `ticks` of the 100 MHz counter, stamps the shader-cycle counter at both ends
+__global__ __launch_bounds__(64) void k_clock_probe(unsigned long long *out, unsigned long long ticks)
+{
+    if (threadIdx.x != 0) return;
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
+    unsigned long long r = r0;
+    while (r - r0 < ticks) {
+        __builtin_amdgcn_s_sleep(64);
+        r = __builtin_amdgcn_s_memrealtime();
+    }
+    unsigned long long *q = out + 3 * (size_t)blockIdx.x;
+    q[0] = __builtin_amdgcn_s_memtime() - c0;
+    q[1] = r - r0;
+    q[2] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 11) | 20) & 0xf;     // HW_REG_XCC_ID, bits 3:0
+}
+}  // namespace
+
+int fdtd2d_clock_probe_start(fdtd2d_t *h, int micros)
+{
+    if (!h || micros < 1 || micros > 10000000) return FDTD2D_E_ARG;
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (!h->clk_dev) {
+        if (hipMalloc((void **)&h->clk_dev, CLK_PROBES * 3 * sizeof(unsigned long long)) != hipSuccess ||
+            hipStreamCreateWithFlags(&h->clk_stream, hipStreamNonBlocking) != hipSuccess)
+            return fail(h, FDTD2D_E_NOMEM, "clock probe buffers");
+    }
+    HIPCHK(h, hipMemsetAsync(h->clk_dev, 0, CLK_PROBES * 3 * sizeof(unsigned long long), h->clk_stream));
+    hipLaunchKernelGGL(k_clock_probe, dim3(CLK_PROBES), dim3(64), 0, h->clk_stream, h->clk_dev,
+                       (unsigned long long)micros * 100ull);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+int fdtd2d_clock_probe_read(fdtd2d_t *h, double *mhz8)
+{
+    if (!h || !mhz8) return FDTD2D_E_ARG;
+    if (!h->clk_dev) return fail(h, FDTD2D_E_STATE, "no clock probe was started");
+    int rc = use_device(h);
+    if (rc) return rc;
+    unsigned long long v[CLK_PROBES * 3];
+    HIPCHK(h, hipStreamSynchronize(h->clk_stream));
+    HIPCHK(h, hipMemcpy(v, h->clk_dev, sizeof v, hipMemcpyDeviceToHost));
+    double sum[8] = {}, cnt[8] = {};
+    for (int k = 0; k < CLK_PROBES; ++k)
+        if (v[3 * k + 1] > 0 && v[3 * k + 2] < 8) {
+            sum[v[3 * k + 2]] += (double)v[3 * k] / (double)v[3 * k + 1] * 100.0;      // cycles per 10 ns tick -> MHz
+            cnt[v[3 * k + 2]] += 1;
+        }
+    for (int x = 0; x < 8; ++x) mhz8[x] = cnt[x] > 0 ? sum[x] / cnt[x] : 0.0;
+    return 0;
 }
 
 int fdtd2d_bytes_per_cell_step(const fdtd2d_t *h)

@@ -58,6 +58,14 @@ __device__ __forceinline__ void staged_level(VecN<T, V> &e, VecN<T, V> &x, VecN<
 #pragma unroll
     for (int v = 0; v + 1 < V; ++v) dy.v[v] = e.v[v + 1] - e.v[v];
     __builtin_amdgcn_sched_barrier(0);
+#ifdef FDTD2D_FUSED      // the tolerance build: x - c * dx and y + c * dy as one v_fma_f32 each (8 instead of 16 here)
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        const T c = ch(v);
+        x.v[v] = __builtin_fmaf(-c, dx.v[v], x.v[v]);
+        y.v[v] = __builtin_fmaf(c, dy.v[v], y.v[v]);
+    }
+#else
 #pragma unroll
     for (int v = 0; v < V; ++v) {
         const T c = ch(v);
@@ -70,6 +78,7 @@ __device__ __forceinline__ void staged_level(VecN<T, V> &e, VecN<T, V> &x, VecN<
         x.v[v] = x.v[v] - dx.v[v];
         y.v[v] = y.v[v] + dy.v[v];
     }
+#endif
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int v = 0; v < V; ++v) dx.v[v] = x.v[v] - pvx.v[v];
@@ -81,11 +90,16 @@ __device__ __forceinline__ void staged_level(VecN<T, V> &e, VecN<T, V> &x, VecN<
 #pragma unroll
     for (int v = 0; v < V; ++v) dy.v[v] = dy.v[v] - dx.v[v];
     __builtin_amdgcn_sched_barrier(0);
+#ifdef FDTD2D_FUSED
+#pragma unroll
+    for (int v = 0; v < V; ++v) e.v[v] = __builtin_fmaf(dy.v[v], ce(v), e.v[v]);
+#else
 #pragma unroll
     for (int v = 0; v < V; ++v) dy.v[v] = dy.v[v] * ce(v);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int v = 0; v < V; ++v) e.v[v] = e.v[v] + dy.v[v];
+#endif
     __builtin_amdgcn_sched_barrier(0);
     }
 }

@@ -58,6 +58,8 @@ template <class T> struct PassParams {
     int src_strip, n_src;      // inner strips [src_strip, src_strip + n_src) hold the source columns: their
     int band_rows_s, nbands_s; // workgroups near the source rows run the slower GENERAL body too and would end
                                // the launch alone, so these strips get short bands of their own (n_src = 0: none)
+    int xcd_map;               // 1: the inner strips' tasks are dealt out XCD by XCD (FDTD2D_OPT_XCD_MAP)
+    int main_pad, main_per, main_tasks, n_inner;   // (with xcd_map) empty blocks in front of them, tasks per XCD, tasks, strips
     int zone_top, zone_bot;    // 1 if this launch owns the grid's top / bottom zone
     int zone_tiles;            // column tiles per zone
     int fused_zones;           // 1: the zone tiles are the first workgroups of the k_bulk launch
@@ -177,7 +179,21 @@ __device__ __forceinline__ bool strip_of_block(const PassParams<T> &p, int b, in
         *rb = min(*ra + p.band_rows_s, p.band_hi);
     } else {
         b -= p.n_src * p.nbands_s;
-        const int sidx = b / p.nbands, band = b - sidx * p.nbands;
+        int sidx, band;
+        if (p.xcd_map) {
+            // Workgroups b, b + 8, b + 16 ... share an XCD (observed round-robin placement; speed only).  XCD x takes
+            // the tasks [x * per, (x + 1) * per) of the list ordered band by band with the strips of a band next to
+            // each other: neighbouring strips run at the same time on the same L2 and fetch the lines they share once.
+            b -= p.main_pad;
+            if (b < 0) return false;
+            const int x = b & 7, q = b >> 3, t = x * p.main_per + q;
+            if (q >= p.main_per || t >= p.main_tasks) return false;
+            band = t / p.n_inner;
+            sidx = t - band * p.n_inner;
+        } else {
+            sidx = b / p.nbands;
+            band = b - sidx * p.nbands;
+        }
         int st = sidx + p.strip_first;
         if (p.n_src > 0 && st >= p.src_strip) st += p.n_src;      // the source strips were dealt with above
         *strip = st;

@@ -35,9 +35,23 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
     p.zone_tiles = (h->cols + D::WZ - 1) / D::WZ;
     // launch order: zone tiles, 2 edge-strip slots (the second stays empty with one strip),
     // then strips 1 .. nstrips-2
-    const long long bulk = 2LL * p.nbands_e + (long long)p.n_src * p.nbands_s +
-                           (long long)p.nbands * std::max(0, p.nstrips - 2 - p.n_src);
+    long long bulk = 2LL * p.nbands_e + (long long)p.n_src * p.nbands_s +
+                     (long long)p.nbands * std::max(0, p.nstrips - 2 - p.n_src);
     const long long zones = (long long)(p.zone_top + p.zone_bot) * p.zone_tiles;
+    p.xcd_map = 0;
+    p.main_pad = p.main_per = p.main_tasks = p.n_inner = 0;
+    if (h->xcd_map && NT >= 8 && h->use_level_split(NT, p.band_lo, p.band_hi) && p.nstrips - 2 - p.n_src > 0) {
+        // (the zone tiles ride in front of the bulk when fused: the pad makes the first inner-strip task a multiple
+        // of 8 in the index the hardware sees)
+        const bool side = zones > 0 && (h->zone_split == 1 || NT > 16);
+        const long long front = (side ? 0 : zones) + 2LL * p.nbands_e + (long long)p.n_src * p.nbands_s;
+        p.xcd_map = 1;
+        p.n_inner = p.nstrips - 2 - p.n_src;
+        p.main_tasks = p.nbands * p.n_inner;
+        p.main_per = (p.main_tasks + 7) / 8;
+        p.main_pad = (int)((8 - front % 8) % 8);
+        bulk = 2LL * p.nbands_e + (long long)p.n_src * p.nbands_s + p.main_pad + 8LL * p.main_per;
+    }
     if (bulk + zones == 0) return 0;
     if constexpr (NT >= 8) {
         if (h->use_level_split(NT, p.band_lo, p.band_hi)) {     // 4 waves per (band, strip), 2 levels each
@@ -206,9 +220,9 @@ template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, 
     p.nstrips = (h->cols + OW - 1) / OW;
     int br = h->stream_band_rows;
     h->shape_now = fdtd2d::Shape{0, 0};
-    if (br <= 0 && h->long_shape.band_rows > 0 && nt == h->cycle_steps()) {
-        h->shape_now = h->long_shape;
-        br = h->long_shape.band_rows;
+    if (const fdtd2d::Shape *gs = br <= 0 ? h->shape_given(nt) : nullptr) {
+        h->shape_now = *gs;
+        br = gs->band_rows;
     }
     if (br <= 0) {
         auto it = h->tuned.find({nt, band_lo, band_hi});
@@ -241,6 +255,7 @@ template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, 
     }
     p.band_rows = std::max(br, 1);
     p.band_rows_e = h->shape_now.edge_rows > 0 ? h->shape_now.edge_rows : p.band_rows;
+    h->last_nt = nt;
     h->shape_last = fdtd2d::Shape{p.band_rows,
                                   h->pml_split(nt) ? 4 : (h->use_level_split(nt, band_lo, band_hi) ? h->split_waves_for(nt, band_lo, band_hi) : 1),
                                   h->pml_split(nt) ? (h->shape_now.edge_rows > 0 ? h->shape_now.edge_rows : h->pml_layer_rows) : p.band_rows_e};
@@ -255,6 +270,7 @@ template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, 
     // a short pass: the nt-step kernel and geometry, advancing only nlev < nt levels (one sweep
     // over the grid for a tail of 3, 5, 6, 7, 9..15 steps instead of one per power of two)
     p.strip_first = 1;
+    p.xcd_map = p.main_pad = p.main_per = p.main_tasks = p.n_inner = 0;
     p.src_strip = p.n_src = 0;
     p.band_rows_s = p.nbands_s = 1;
     p.nlev = nlev > 0 ? std::min(nlev, nt) : nt;

@@ -299,6 +299,20 @@ int fdtd2d_slab_detach(fdtd2d_t *h)
     return 0;
 }
 
+long long fdtd2d_slab_ranks(fdtd2d_t *h)
+{
+    if (!h) return FDTD2D_E_ARG;
+    fdtd2d_slab *s = slab_of(h);
+    if (!s) return fail(h, FDTD2D_E_STATE, "no slab loop attached");
+    if (!s->comm) return 0;
+    auto count = (int (*)(void *, int *))dlsym(s->lib, "ncclCommCount");
+    auto urank = (int (*)(void *, int *))dlsym(s->lib, "ncclCommUserRank");
+    int n = 0, r = 0;
+    if (!count || !urank || count(s->comm, &n) || urank(s->comm, &r))
+        return fail(h, FDTD2D_E_STATE, "ncclCommCount / ncclCommUserRank failed");
+    return (long long)r * 65536 + n;
+}
+
 int fdtd2d_run_slab(fdtd2d_t *h, int nsteps, int cycle, int overlap, int src_row, int src_col, const double *amps)
 {
     if (!h) return FDTD2D_E_ARG;

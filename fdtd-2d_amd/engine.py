@@ -294,7 +294,7 @@ class Engine:
         return self
 
     def set_option(self, max_pass_steps=None, band_rows=None, zone_split=None, level_split=None,
-                   split_waves=None, autotune=None, long_shape=None):
+                   split_waves=None, autotune=None, long_shape=None, xcd_map=None):
         """Speed knobs of run(): longest temporally blocked pass (0 = single-step kernels
         only) and rows per streaming band.  Results do not depend on them."""
         if max_pass_steps is not None:
@@ -309,10 +309,13 @@ class Engine:
             self._ck(self._lib.fdtd2d_set_option(self._h, _abi.OPT_AUTOTUNE, int(bool(autotune))))
         if split_waves is not None:
             self._ck(self._lib.fdtd2d_set_option(self._h, _abi.OPT_SPLIT_WAVES, int(split_waves)))
-        if long_shape is not None:       # (band rows, waves per strip) of the full-length passes
-            br, nw, *er = long_shape
+        if xcd_map is not None:
+            self._ck(self._lib.fdtd2d_set_option(self._h, _abi.OPT_XCD_MAP, int(xcd_map)))
+        if long_shape is not None:       # (band rows, waves per strip[, edge band rows[, pass length]]); pass
+            br, nw, *er = long_shape     # length 0 / absent = the full-length passes
             self._ck(self._lib.fdtd2d_set_option(self._h, _abi.OPT_LONG_SHAPE,
-                                                 int(br) + 65536 * int(nw) + (int(er[0]) << 32 if er else 0)))
+                                                 int(br) + 65536 * int(nw) + (int(er[0]) << 32 if er else 0)
+                                                 + (int(er[1]) << 48 if len(er) > 1 else 0)))
         return self
 
     def sync(self):
@@ -374,6 +377,14 @@ class Engine:
         if rc:
             raise _abi.Fdtd2dError(rc, lib.fdtd2d_last_error(None).decode())
 
+    def slab_ranks(self):
+        """(rank, ranks) of the RCCL communicator behind the built-in transport as RCCL reports them; None for a
+        caller-supplied transport."""
+        v = int(self._lib.fdtd2d_slab_ranks(self._h))
+        if v < 0:
+            self._ck(v)
+        return (v >> 16, v & 0xffff) if v else None
+
     def run_slab(self, nsteps, cycle, overlap, src_row=0, src_col=0, amps=None):
         ap = None
         if amps is not None:
@@ -405,6 +416,16 @@ class Engine:
         self._ck(self._lib.fdtd2d_reduce(self._h, f, C.byref(s), C.byref(m)))
         return float(s.value), float(m.value)
 
+    def clock_probe_start(self, micros):
+        """Start the shader-clock probe (runs for `micros` us beside whatever is launched next)."""
+        self._ck(self._lib.fdtd2d_clock_probe_start(self._h, int(micros)))
+
+    def clock_probe_read(self):
+        """Shader clock in MHz per XCC id (0.0 where no probe workgroup landed)."""
+        out = (C.c_double * 8)()
+        self._ck(self._lib.fdtd2d_clock_probe_read(self._h, out))
+        return [float(v) for v in out]
+
     def timer_start(self):
         self._ck(self._lib.fdtd2d_timer_start(self._h))
 
@@ -423,6 +444,11 @@ class Engine:
     def last_shape(self):
         """(band rows, waves per strip, band rows of the first / last strip) of the last pass."""
         return self.info(_abi.INFO_LAST_BAND_ROWS), self.info(_abi.INFO_LAST_WAVES), self.info(_abi.INFO_LAST_EDGE_ROWS)
+
+    @property
+    def last_pass_steps(self) -> int:
+        """Kernel length (1, 2, 4, 8, 16 or 20 steps) of the last temporally blocked pass; 0 before the first."""
+        return self.info(_abi.INFO_LAST_PASS_STEPS)
 
     @property
     def cycle_steps(self) -> int:

@@ -83,6 +83,7 @@ typedef struct fdtd2d fdtd2d_t;
 #define FDTD2D_INFO_LAST_BAND_ROWS 19 /* band height of the last temporally blocked pass */
 #define FDTD2D_INFO_LAST_WAVES    20 /* its waves per (band, strip): 1 (k_bulk), 4 or 8 (k_bulk_split) */
 #define FDTD2D_INFO_LAST_EDGE_ROWS 21 /* its band height on the first / last strip */
+#define FDTD2D_INFO_LAST_PASS_STEPS 22 /* the kernel length (1, 2, 4, 8, 16, 20) of the last pass; 0: none yet */
 #define FDTD2D_INFO_CYCLE_STEPS   18 /* longest pass the current configuration runs: 16 (float32, Mur
                                          frame, >= 12 Mi cells per GPU), else 8, 0 if passes are off */
 
@@ -240,10 +241,16 @@ int fdtd2d_sync(fdtd2d_t *h);
                                          times a ladder of band heights (and 4 / 8 waves per strip)
                                          with uncommitted trial launches and keeps the fastest;
                                          0: fixed rules.  Results are identical either way. */
-#define FDTD2D_OPT_LONG_SHAPE      6   /* launch shape of the full-length passes (16 or 8 steps), value =
-                                         band rows + 65536 * waves per strip (0 = automatic) + 2^32 * band
-                                         rows of the first / last strip (0 = the same): re-use a shape
-                                         the tuner found in another process; 0 clears it */
+#define FDTD2D_OPT_LONG_SHAPE      6   /* launch shape of the passes of one length, value = band rows + 2^16 *
+                                         waves per strip (0 = automatic) + 2^32 * band rows of the first /
+                                         last strip (0 = the same) + 2^48 * pass length (0 = the full-length
+                                         passes, 16 or 8 steps; 20 = the 20-step remainder pass): re-use a
+                                         shape the tuner found in another process; band rows 0 clears it */
+#define FDTD2D_OPT_XCD_MAP         7   /* task order of the level-split pass: 1 = every XCD (workgroups b, b + 8, ...
+                                         under the round-robin placement the hardware is observed to use) gets a
+                                         contiguous run of (band, strip) tasks with the strips of one band next to
+                                         each other, so that the cache lines neighbouring strips share are fetched
+                                         once per XCD L2; 0 = all bands of one strip consecutive.  Speed only. */
 int fdtd2d_set_option(fdtd2d_t *h, int option, long long value);
 
 /* ---- row-slab halo exchange (transport is the caller's: RCCL via torch.distributed) -- */
@@ -291,6 +298,9 @@ int fdtd2d_rccl_unique_id(void *out128);
 int fdtd2d_rccl_selftest(int device, long long count);
 int fdtd2d_slab_attach_rccl(fdtd2d_t *h, const void *unique_id128, int rank, int world);
 int fdtd2d_slab_detach(fdtd2d_t *h);
+/* Ranks of the communicator behind the attached transport as RCCL itself counts them (ncclCommCount) and this
+ * handle's rank in it (ncclCommUserRank): rank * 65536 + count; 0 for a caller-supplied transport; < 0 on error. */
+long long fdtd2d_slab_ranks(fdtd2d_t *h);
 int fdtd2d_run_slab(fdtd2d_t *h, int nsteps, int cycle, int overlap, int src_row, int src_col,
                     const double *amps);
 
@@ -322,12 +332,23 @@ int fdtd2d_time_launches(fdtd2d_t *h, int nlaunch, int steps_each, float *ms);
 
 /* Algorithmic HBM bytes per cell-step of the current configuration (SURVEY.md
  * section 8 M2): 24 + 4 per non-uniform coefficient array, times sizeof(T)/4. */
+/* Shader clock under load: _start enqueues (on an internal side stream, NOT ordered with the handle's stream) 16
+ * single-wave workgroups that sleep for `micros` microseconds and stamp the shader-cycle counter (s_memtime) against
+ * the constant 100 MHz counter (s_memrealtime) at both ends; launch the work to be observed right after it.
+ * _read waits for them and returns the clock in MHz per XCC id (0 where no probe landed).  Measurement aid. */
+int fdtd2d_clock_probe_start(fdtd2d_t *h, int micros);
+int fdtd2d_clock_probe_read(fdtd2d_t *h, double *mhz8);
+
 int fdtd2d_bytes_per_cell_step(const fdtd2d_t *h);
 
 /* Device pointer of a field's storage (row-major, pitch elements per row, first
  * stored row = global row row0-halo) for zero-copy interop.  NULL on error. */
 void *fdtd2d_device_ptr(fdtd2d_t *h, int field);
 
+/* Names the build: libfdtd2d.so = "... one rounding per operation: value-identical build" (-ffp-contract=off),
+ * libfdtd2d_fused.so = "... fused multiply-add: tolerance build" (the same sources with a*b+c contracted into FMA:
+ * 8 instead of 11 operations per cell-step, results within rounding of the exact build -- SURVEY.md M3's fp32
+ * tolerance -- and still independent of the launch shape). */
 const char *fdtd2d_version(void);
 
 #ifdef __cplusplus

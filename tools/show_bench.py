@@ -1,14 +1,11 @@
-#!/usr/bin/env python3
-"""Condensed view of a bench.py JSON line: python tools/show_bench.py file.json"""
-import json, sys
-for path in sys.argv[1:]:
-  d = json.loads([l for l in open(path).read().splitlines() if l.startswith("{")][-1])
-  print("==", path)
-  for r in [d] + d.get("secondary", []):
-      rl = r["roofline"]
-      print(r["config"]["grid"], r["config"]["materials"], r["config"]["boundary"], "steps", r["steps"], "value", r["value"],
-            "| steady", rl.get("steady_state_value"), "launch_ms", rl.get("avg_launch_ms"), "incl_gaps", rl.get("avg_launch_ms_incl_gaps"),
-            "| frac", rl.get("frac"), "overfetch", rl.get("overfetch"), "valu", rl.get("valu_frac"), "alg x_peak", rl["algorithmic"]["x_peak"],
-            "| shape", rl.get("launch_shape"), rl.get("traffic_note", ""))
-  if "cpu_baseline" in d:
-      print("cpu:", d["cpu_baseline"])
+import json,sys
+for f in sys.argv[1:]:
+    try: d=json.load(open(f))
+    except Exception as e: print(f, "ERR", e); continue
+    r=d['roofline']; ss=r.get('steady_state',{})
+    print(f, 'value', d['value'], d['value_min_max'], 'run', r['kernel'], 'frac', r['frac'], 'of', r['overfetch'], 'valu', r['valu_frac'])
+    print('   ss', ss.get('avg_launch_ms'), ss.get('value'), 'frac', ss.get('frac'), 'of', ss.get('overfetch'), 'valu', ss.get('valu_frac'), 'rw', ss.get('traffic_read_write'), ss.get('launch_shape'))
+    for k,v in ss.get('clock_vs_launch',{}).items(): print('   ', k, v['mhz_ms_per_8_launch_group'][-3:], v['value'])
+    for s in d.get('secondary',[]):
+        rr=s['roofline']; s2=rr.get('steady_state',{})
+        print('   sec', s['config']['workload'][:44], s['dtype'], s['value'], 'frac', rr['frac'], 'of', rr['overfetch'], 'ss', s2.get('value'), s2.get('avg_launch_ms'))

@@ -243,9 +243,10 @@ def make_engine(fd, rows, cols, materials, device, boundary, shapes=None, autotu
         eng.set_option(autotune=False)
     if ENGINE_OPTS:
         eng.set_option(**ENGINE_OPTS)
-    for nt, shp in (shapes or {}).items():       # {pass length: (band rows, waves, edge rows)}
+    for nt, shp in (shapes or {}).items():       # {pass length: (band rows, waves, edge rows, waves side by side, xcd map)}
         if shp and shp[0]:
-            eng.set_option(long_shape=(shp[0], shp[1], shp[2], int(nt) if int(nt) != eng.cycle_steps else 0))
+            shp = list(shp) + [0] * (5 - len(shp))
+            eng.set_option(long_shape=(shp[0], shp[1], shp[2], int(nt) if int(nt) != eng.cycle_steps else 0, shp[3], shp[4]))
     return eng
 
 
@@ -259,6 +260,7 @@ def time_single(fd, rows, cols, steps, warmup, materials, device, boundary="mur"
     eng.prepare(steps, sr, sc)  # launch-shape tuner (trial launches, state untouched): part of set-up
     eng.run(warmup, sr, sc, amplitudes(fd, 0, warmup)).sync()
     cyc = eng.cycle_steps
+    copy = [eng.measure_copy(4)]        # what a plain copy of the same arrays reaches on this device right now
     walls, events, first = [], [], warmup
     l0 = eng.info(16), eng.info(17)
     if gpu is not None:
@@ -286,6 +288,8 @@ def time_single(fd, rows, cols, steps, warmup, materials, device, boundary="mur"
         one = np.sort(eng.time_launches(48, cyc))
         res["launch_ms"] = float(np.mean(one[4:-4]))       # trimmed mean of back-to-back launches
         res["launch_ms_minmax"] = [float(one[0]), float(one[-1])]
+    copy.append(eng.measure_copy(4))
+    res["copy_gbps"] = [round(v, 1) for v in copy]
     if gpu is not None:
         res["gpu_during"] = gpu.summary()
     if cyc and clock_groups:
@@ -319,7 +323,7 @@ def _shape_args(shapes):
     out = []
     for nt, shp in (shapes or {}).items():
         if shp and shp[0]:
-            out += ["--shape", f"{int(nt)}:{int(shp[0])}:{int(shp[1])}:{int(shp[2])}"]
+            out += ["--shape", ":".join(str(int(v)) for v in [nt, *shp])]
     return out
 
 
@@ -330,8 +334,8 @@ def pmc_child(args):
     import fdtd2d_amd as fd
     shapes = {}
     for s in args.shape or []:
-        nt, br, nw, er = (int(v) for v in s.split(":"))
-        shapes[nt] = (br, nw, er)
+        nt, *rest = (int(v) for v in s.split(":"))
+        shapes[nt] = tuple(rest)
     eng = make_engine(fd, args.grid, args.cols, args.materials, 0, args.boundary, shapes, dtype=NP_DTYPE[args.dtype])
     K, cyc = args.child_steps, eng.cycle_steps
     sr, sc = args.grid // 2, args.cols // 2
@@ -459,8 +463,8 @@ def roofline_block(cells, steps, r, traffic):
            "traffic_source": None, "overfetch": None, "valu_frac": None,
            "kernel": None, "kernels": None, "passes_per_run": passes, "steps_per_run": steps,
            "run_event_ms": {"median": round(ev, 5), "min": round(min(r["events_ms"]), 5), "max": round(max(r["events_ms"]), 5)},
-           "launch_shape": {"band_rows": r["run_shape"][0], "waves_per_strip": r["run_shape"][1],
-                            "edge_strip_band_rows": r["run_shape"][2], "pass_steps": r["run_last_nt"]},
+           "launch_shape": dict(zip(("band_rows", "waves_per_level_group", "edge_strip_band_rows", "waves_side_by_side",
+                                     "xcd_map"), r["run_shape"]), pass_steps=r["run_last_nt"]),
            "algorithmic": {"bytes_per_cell_step": bpc, "bytes_per_run": int(alg_bytes),
                            "rate_GBps": round(alg_bytes / (ev * 1e-3) / 1e9, 1),
                            "x_peak": round(alg_bytes / (ev * 1e-3) / 1e9 / HBM_PEAK_GBS, 3)}}
@@ -482,8 +486,8 @@ def roofline_block(cells, steps, r, traffic):
         ms, spl = r["launch_ms"], r["launch_steps"]
         ss = {"steps_per_launch": spl, "avg_launch_ms": round(ms, 5), "launch_ms_min_max": [round(v, 5) for v in r["launch_ms_minmax"]],
               "value": round(cells * spl / (ms * 1e-3) / 1e6, 1),
-              "launch_shape": {"band_rows": r["full_shape"][0], "waves_per_strip": r["full_shape"][1],
-                               "edge_strip_band_rows": r["full_shape"][2]},
+              "launch_shape": dict(zip(("band_rows", "waves_per_level_group", "edge_strip_band_rows", "waves_side_by_side",
+                                        "xcd_map"), r["full_shape"])),
               "algorithmic_x_peak": round(cells * spl * bpc / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 3)}
         if isinstance(traffic, dict) and "full" in traffic and traffic["cycle"] == spl:
             t = traffic["full"]
@@ -517,6 +521,7 @@ def single_record(fd, rows, cols, steps, warmup, materials, boundary, device, pm
                                   + " boundary, ricker point source at the centre" + note,
                       "grid": [rows, cols], "materials": materials, "boundary": boundary},
            "roofline": roofline_block(cells, steps, r, traffic)}
+    rec["roofline"]["copy_kernel_GBps_before_after"] = r["copy_gbps"]
     if "gpu_during" in r:
         rec["gpu_during"] = r["gpu_during"]
     if "clock_vs_launch" in r:
@@ -615,7 +620,8 @@ def main():
     ap.add_argument("--no-autotune", action="store_true",
                     help="fixed launch-shape rules (for profiler runs: the tuner's trial launches would be "
                          "averaged into the per-kernel statistics); combine with --shape")
-    ap.add_argument("--shape", action="append", help="pass length:band rows:waves:edge band rows (repeatable)")
+    ap.add_argument("--shape", action="append",
+                    help="pass length:band rows:waves:edge band rows[:waves side by side:xcd map] (repeatable)")
     ap.add_argument("--opt", action="append", default=[], help="Engine.set_option knob, name=int (repeatable; experiments)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--child-steps", type=int, default=16, help=argparse.SUPPRESS)

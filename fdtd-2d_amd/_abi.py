@@ -24,7 +24,7 @@ BOUNDARY_NONE, BOUNDARY_MUR5, BOUNDARY_PML = 0, 1, 2
 SRC_NONE, SRC_RICKER, SRC_SINUSOIDAL = 0, 1, 2
 FIELD_EZ, FIELD_HX, FIELD_HY = 0, 1, 2
 
-OPT_MAX_PASS_STEPS, OPT_BAND_ROWS, OPT_ZONE_SPLIT, OPT_LEVEL_SPLIT, OPT_SPLIT_WAVES, OPT_AUTOTUNE, OPT_LONG_SHAPE, OPT_XCD_MAP = 0, 1, 2, 3, 4, 5, 6, 7
+OPT_MAX_PASS_STEPS, OPT_BAND_ROWS, OPT_ZONE_SPLIT, OPT_LEVEL_SPLIT, OPT_SPLIT_WAVES, OPT_AUTOTUNE, OPT_LONG_SHAPE, OPT_XCD_MAP, OPT_SIDE_WAVES = 0, 1, 2, 3, 4, 5, 6, 7, 8
 
 E_ARG, E_NODEVICE, E_NOMEM, E_STATE, E_COURANT = -1, -2, -3, -4, -5
 
@@ -32,7 +32,7 @@ E_ARG, E_NODEVICE, E_NOMEM, E_STATE, E_COURANT = -1, -2, -3, -4, -5
  INFO_BOUNDARY, INFO_DEVICE, INFO_EPS_UNIFORM, INFO_MU_UNIFORM, INFO_E_VALID_LO,
  INFO_E_VALID_HI, INFO_H_VALID_LO, INFO_H_VALID_HI, INFO_STEP, INFO_PASS_LAUNCHES,
  INFO_STEP_LAUNCHES, INFO_CYCLE_STEPS, INFO_LAST_BAND_ROWS, INFO_LAST_WAVES, INFO_LAST_EDGE_ROWS,
- INFO_LAST_PASS_STEPS) = range(23)
+ INFO_LAST_PASS_STEPS, INFO_LAST_SIDE_WAVES, INFO_LAST_XCD_MAP) = range(25)
 
 _vp, _i, _d, _ll = C.c_void_p, C.c_int, C.c_double, C.c_longlong
 
@@ -83,6 +83,7 @@ SIGNATURES = {
     "fdtd2d_timer_stop": (_i, [_vp, C.POINTER(C.c_float)]),
     "fdtd2d_time_launches": (_i, [_vp, _i, _i, C.POINTER(C.c_float)]),
     "fdtd2d_clock_probe_start": (_i, [_vp, _i]),
+    "fdtd2d_measure_copy": (_i, [_vp, _i, C.POINTER(_d)]),
     "fdtd2d_clock_probe_read": (_i, [_vp, C.POINTER(_d)]),
     "fdtd2d_bytes_per_cell_step": (_i, [_vp]),
     "fdtd2d_device_ptr": (_vp, [_vp, _i]),

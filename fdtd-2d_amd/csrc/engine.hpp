@@ -132,7 +132,18 @@ struct fdtd2d {
         int band_rows, waves;
         int edge_rows = 0;       // band height of the first / last strip (0 = band_rows): their body
                                  // is ~2x slower per row, equal heights make them the tail of a launch
+        int side = 1;            // waves side by side per level group (1, 2 or 4; kernels_stream.hpp, strip_x0)
+        int xcd = 0;             // 1: tasks dealt out XCD by XCD (FDTD2D_OPT_XCD_MAP), chosen per shape by the tuner
     };
+    // strips of several waves side by side exist for the float32 16- and 20-step level-split kernels with 4 waves
+    // per level group, on grids wide enough for a few of them
+    bool side_ok(int nt, int sd) const
+    {
+        if (sd == 1) return true;
+        // (4 waves side by side = 1024 threads, at most 128 VGPRs each: only without coefficient rows in the slots)
+        return (sd == 2 || (sd == 4 && ce_uniform && ch_uniform)) && dtype == FDTD2D_F32 &&
+               boundary == FDTD2D_BOUNDARY_MUR5 && (nt == 16 || nt == 20) && cols >= 8 * 256 * sd;
+    }
     std::map<std::array<int, 3>, Shape> tuned;
     int autotune = 1;            // FDTD2D_OPT_AUTOTUNE
     // FDTD2D_OPT_LONG_SHAPE: launch shapes given by the caller (measured elsewhere, e.g. by another process), by
@@ -175,7 +186,8 @@ struct fdtd2d {
             return 16;
         return std::min(max_nt, 8);
     }
-    int xcd_map = 0;             // FDTD2D_OPT_XCD_MAP
+    int xcd_map = -1;            // FDTD2D_OPT_XCD_MAP: -1 = the tuner's choice per shape, 0 / 1 forced
+    int side_waves = 0;          // FDTD2D_OPT_SIDE_WAVES: 0 = the tuner's choice, 1 / 2 / 4 forced
     unsigned long long *clk_dev = nullptr;   // clock probe stamps (fdtd2d_clock_probe_*)
     hipStream_t clk_stream = nullptr;
     int zone_split = -1;         // -1: by launch size; 0/1: force fused / side-stream zones (FDTD2D_OPT_ZONE_SPLIT)

@@ -677,6 +677,8 @@ long long fdtd2d_info(const fdtd2d_t *h, int what)
     case FDTD2D_INFO_LAST_WAVES: return h->shape_last.waves;
     case FDTD2D_INFO_LAST_EDGE_ROWS: return h->shape_last.edge_rows;
     case FDTD2D_INFO_LAST_PASS_STEPS: return h->last_nt;
+    case FDTD2D_INFO_LAST_SIDE_WAVES: return h->shape_last.side;
+    case FDTD2D_INFO_LAST_XCD_MAP: return h->shape_last.xcd;
     default: return FDTD2D_E_ARG;
     }
 }
@@ -957,11 +959,23 @@ static int tune_pass(fdtd2d *h, int nt, int lo, int hi, bool zt, bool zb, int sr
     const std::vector<int> ladder = nt >= 16 ? std::vector<int>{64, 96, 144, 208, 304, 448}
                                              : std::vector<int>{16, 24, 32, 48, 64, 96, 128};
     const bool both_nw = split && nt == 16 && !h->split_waves;
-    for (int nw : {4, 8}) {
-        if (nw == 8 && !both_nw) continue;
-        for (int br : ladder)
-            if (br * 4 <= hi - lo) cand.push_back({br, both_nw ? nw : 0});
+    // waves side by side per level group (strips 256, 504 or 1000 columns wide): the caller's choice or every width
+    // the configuration has (float32 16- / 20-step level-split passes, 4 waves per level group)
+    std::vector<int> sides{1};
+    if (split && !h->pml_split(nt) && (h->split_waves == 0 || h->split_waves == 4)) {
+        if (h->side_waves > 1) {
+            if (h->side_ok(nt, h->side_waves)) sides = {h->side_waves};
+        } else if (h->side_waves == 0) {
+            for (int sd : {2, 4})
+                if (h->side_ok(nt, sd)) sides.push_back(sd);
+        }
     }
+    for (int sd : sides)
+        for (int nw : {4, 8}) {
+            if (nw == 8 && (!both_nw || sd > 1)) continue;
+            for (int br : ladder)
+                if (br * 4 <= hi - lo) cand.push_back({br, (both_nw || sd > 1) ? nw : 0, 0, sd});
+        }
     if (h->pml_split(nt))                       // the PML pair: plain band height x band height of the layer's end strips
         for (int re : {128, 256})
             for (int br : ladder)
@@ -974,20 +988,23 @@ static int tune_pass(fdtd2d *h, int nt, int lo, int hi, bool zt, bool zb, int sr
     // workgroups 184: profiles/r02_shape_sweep.txt)
     if (split) {
         const int region = hi - lo, V = h->dtype == FDTD2D_F32 ? 4 : 2;
-        const int ow = 64 * V - 2 * fdtd::stream_hc(nt);
+        for (int sd : sides) {
+        const int wt = sd > 1 ? fdtd::strip_width(nt / 4, V, sd) : 64 * V;
+        const int ow = wt - 2 * fdtd::stream_hc(nt);
         const int ns = (h->cols + ow - 1) / ow;
-        const int zw = nt == 16 ? 30 : (nt == 8 ? 14 : 0);   // ZoneDims<NT>::WZ (24 steps: zones run beside the bulk)
+        // ZoneDims<NT>::WZ; 20-step passes and strips of several waves take their zones from k_zone beside the bulk
+        const int zw = sd > 1 ? 0 : (nt == 16 ? 30 : (nt == 8 ? 14 : 0));
         const int zones = zw ? ((zt ? 1 : 0) + (zb ? 1 : 0)) * ((h->cols + zw - 1) / zw) : 0;
         int n_src = 0;                           // inner strips that hold source columns (bands of their own)
         for (int st = 1; has_src && st <= ns - 2; ++st) {
             const int x0 = st * ow - fdtd::stream_hc(nt);
-            if (src_col + h->src_cols > x0 && src_col < x0 + 64 * V) ++n_src;
+            if (src_col + h->src_cols > x0 && src_col < x0 + wt) ++n_src;
         }
         if (n_src > 2) n_src = 0;
         for (int nw : {4, 8}) {
-            if (nw == 8 && !both_nw) continue;
-            // resident workgroups (VGPR / LDS limits): 4 x 4 waves or 2 x 8 per CU
-            const int slots = 256 * (nw == 8 ? 2 : 4);
+            if (nw == 8 && (!both_nw || sd > 1)) continue;
+            // resident workgroups (VGPR / LDS limits): 16 waves per CU
+            const int slots = 256 * (nw == 8 ? 2 : 4) / sd;
             const double fill = 2.0 * nt + nw - 1;
             for (int k : {1, 2, 3, 4}) {
                 for (double w_e : {1.0, 2.0, 3.0}) {            // edge bands as tall, 1/2, 1/3 as long-lived
@@ -1000,12 +1017,13 @@ static int tune_pass(fdtd2d *h, int nt, int lo, int hi, bool zt, bool zb, int sr
                         const int brs = std::max(16, std::min((region + ne - 1) / ne, (region + nb - 1) / nb / 3));
                         const int n_s = n_src * ((region + brs - 1) / brs);          // workgroups of the source strips
                         if ((double)std::max(0, ns - 2 - n_src) * nb + 2.0 * ne + n_s > tasks) break;
-                        best = fdtd2d::Shape{(region + nb - 1) / nb, both_nw ? nw : 0,
-                                             w_e == 1.0 ? 0 : std::max(8, (region + ne - 1) / ne)};
+                        best = fdtd2d::Shape{(region + nb - 1) / nb, (both_nw || sd > 1) ? nw : 0,
+                                             w_e == 1.0 ? 0 : std::max(8, (region + ne - 1) / ne), sd};
                     }
                     if (best.band_rows >= 8) cand.push_back(best);
                 }
             }
+        }
         }
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1082,16 +1100,47 @@ static int tune_pass(fdtd2d *h, int nt, int lo, int hi, bool zt, bool zb, int sr
     std::vector<size_t> order(cand.size());
     for (size_t n = 0; n < order.size(); ++n) order[n] = n;
     std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return best_of[a] < best_of[b]; });
+    // the fastest four go to the finals -- together with their twins whose tasks are dealt out XCD by XCD
+    // (FDTD2D_OPT_XCD_MAP: worth 3-5 % on launches of several rounds, -7 % on one-round launches) unless the caller
+    // has fixed that choice
+    {
+        // (the fastest four, and the fastest two of every strip width: the widths respond differently to the
+        // XCD-wise order -- 16384^2: 1 wave per level group 1549 -> 1467 us, 4 side by side 1507 -> 1507)
+        std::vector<fdtd2d::Shape> fin;
+        std::vector<float> fin_ms;
+        int per_side[5] = {0, 0, 0, 0, 0};
+        for (size_t k = 0; k < order.size(); ++k) {
+            const fdtd2d::Shape &c = cand[order[k]];
+            const int sd = std::min(std::max(c.side, 1), 4);
+            if (k < 4 || per_side[sd] < 2) {
+                fin.push_back(c);
+                fin_ms.push_back(best_of[order[k]]);
+            }
+            per_side[sd]++;
+        }
+        if (split && h->xcd_map < 0 && !h->pml_split(nt))
+            for (size_t k = 0, n = fin.size(); k < n; ++k) {
+                fdtd2d::Shape t = fin[k];
+                t.xcd = 1;
+                fin.push_back(t);
+                fin_ms.push_back(fin_ms[k]);
+            }
+        cand = fin;
+        best_of = fin_ms;
+        order.resize(cand.size());
+        for (size_t n = 0; n < order.size(); ++n) order[n] = n;
+    }
     fdtd2d::Shape best = cand[order[0]];
     float best_ms = 1e30f;
-    const size_t finalists = std::min<size_t>(4, order.size());
+    const size_t finalists = order.size();
     for (int round = 0; round < 3 && rc == 0; ++round)
         for (size_t k = 0; k < finalists && rc == 0; ++k) {
             float ms = 0;
             if ((rc = timed(cand[order[k]], 6, &ms))) break;
 #ifdef FDTD2D_TUNE_LOG      // profiling builds only (tools/): what the tuner saw
-            fprintf(stderr, "tune nt=%d final %d: (%d, %d, %d) first rounds %.4f ms, now %.4f ms\n", nt, round,
-                    cand[order[k]].band_rows, cand[order[k]].waves, cand[order[k]].edge_rows, best_of[order[k]], ms);
+            fprintf(stderr, "tune nt=%d final %d: (%d, %d, %d, side %d, xcd %d) first rounds %.4f ms, now %.4f ms\n", nt, round,
+                    cand[order[k]].band_rows, cand[order[k]].waves, cand[order[k]].edge_rows, cand[order[k]].side,
+                    cand[order[k]].xcd, best_of[order[k]], ms);
 #endif
             // (8 waves per strip run 5-7 % slower on a run's real fields than in these trials on the fields at
             // hand -- zero in a fresh engine: 8192^2 ring map 0.53 ms in trials, 0.57 ms in the run, while the
@@ -1321,16 +1370,23 @@ int fdtd2d_set_option(fdtd2d_t *h, int option, long long value)
         h->tuned.clear();
         return 0;
     case FDTD2D_OPT_XCD_MAP:
-        if (value != 0 && value != 1) return fail(h, FDTD2D_E_ARG, "xcd map must be 0 or 1");
+        if (value < -1 || value > 1) return fail(h, FDTD2D_E_ARG, "xcd map must be -1, 0 or 1");
         h->xcd_map = (int)value;
+        h->tuned.clear();
+        return 0;
+    case FDTD2D_OPT_SIDE_WAVES:
+        if (value != 0 && value != 1 && value != 2 && value != 4) return fail(h, FDTD2D_E_ARG, "side waves must be 0, 1, 2 or 4");
+        h->side_waves = (int)value;
         h->tuned.clear();
         return 0;
     case FDTD2D_OPT_LONG_SHAPE: {
         const int br = (int)(value & 0xffff), nw = (int)((value >> 16) & 0xffff), er = (int)((value >> 32) & 0xffff);
         const int nt = (int)((value >> 48) & 0xff);       // 0: the full-length passes
-        if (value < 0 || (nw != 0 && nw != 4 && nw != 8) || nt > fdtd::STREAM_MAX_NT)
-            return fail(h, FDTD2D_E_ARG, "shape = band rows + 2^16 * waves (0, 4 or 8) + 2^32 * edge band rows + 2^48 * pass length");
-        h->given_shape[nt] = fdtd2d::Shape{br, nw, er};
+        const int sd = (int)((value >> 56) & 0x7), xc = (int)((value >> 59) & 0x1);
+        if (value < 0 || (nw != 0 && nw != 4 && nw != 8) || nt > fdtd::STREAM_MAX_NT || (sd != 0 && sd != 1 && sd != 2 && sd != 4))
+            return fail(h, FDTD2D_E_ARG, "shape = band rows + 2^16 * waves (0, 4 or 8) + 2^32 * edge band rows + 2^48 * pass length "
+                                         "+ 2^56 * waves side by side (0, 1, 2, 4) + 2^59 * xcd map");
+        h->given_shape[nt] = fdtd2d::Shape{br, nw, er, sd ? sd : 1, xc};
         return 0;
     }
     default: return fail(h, FDTD2D_E_ARG, "unknown option %d", option);
@@ -1531,6 +1587,39 @@ __global__ __launch_bounds__(64) void k_clock_probe(unsigned long long *out, uns
     q[2] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 11) | 20) & 0xf;     // HW_REG_XCC_ID, bits 3:0
 }
 }  // namespace
+
+namespace {
+__global__ __launch_bounds__(256) void k_copy16(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+}  // namespace
+
+int fdtd2d_measure_copy(fdtd2d_t *h, int reps, double *gbps)
+{
+    int rc = need_stable(h);
+    if (rc) return rc;
+    if (!gbps || reps < 1 || reps > 1000) return fail(h, FDTD2D_E_ARG, "bad arguments");
+    if (h->pend_nt) return fail(h, FDTD2D_E_STATE, "a partial pass is pending: commit it first");
+    const size_t n = h->field_bytes / 16;
+    const void *src[3] = {h->ez[h->cur], h->hxb[h->hcur], h->hyb[h->hcur]};
+    void *dst[3] = {h->ez[h->cur ^ 1], h->hxb[h->hcur ^ 1], h->hyb[h->hcur ^ 1]};
+    auto once = [&]() {
+        for (int f = 0; f < 3; ++f)
+            hipLaunchKernelGGL(k_copy16, dim3(256 * 16), dim3(256), 0, h->stream, (const uint4 *)src[f], (uint4 *)dst[f], n);
+    };
+    once();                                  // first touch
+    HIPCHK(h, hipEventRecord(h->t0, h->stream));
+    for (int r = 0; r < reps; ++r) once();
+    HIPCHK(h, hipEventRecord(h->t1, h->stream));
+    HIPCHK(h, hipEventSynchronize(h->t1));
+    HIPCHK(h, hipGetLastError());
+    float ms = 0;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->t0, h->t1));
+    *gbps = ms > 0 ? 2.0 * 3.0 * (double)(n * 16) * reps / (ms * 1e-3) / 1e9 : 0.0;
+    return 0;
+}
 
 int fdtd2d_clock_probe_start(fdtd2d_t *h, int micros)
 {

@@ -202,26 +202,30 @@ constexpr int HAND_DEPTH = 2;
 // microbenchmark.  Same values, 118 VGPRs, but 10 % SLOWER at 4096^2 (150.5 vs 136 us), 5 % at 8192^2, 1 % at 16384^2:
 // four cone checks per level instead of one and 4-wide instead of 8-wide stages cost more than the shifts do.)
 // ROLE 0: first wave (HBM -> LDS), 1: middle (LDS -> LDS), 2: last (LDS -> HBM)
-template <class T, int NT, int SPLIT_NW, bool CE_ARR, bool CH_ARR, bool GENERAL, int ROLE, int V>
+template <class T, int NT, int SPLIT_NW, bool CE_ARR, bool CH_ARR, bool GENERAL, int ROLE, int V, int SD = 1>
 __device__ __forceinline__ void split_body(const PassParams<T> &p, const int strip, const int ra,
-                                           const int rb, const int w, VecN<T, V> *lds)
+                                           const int rb, const int w, const int side, VecN<T, V> *lds)
 {
     using M = StripMath<T, GENERAL, CE_ARR, CH_ARR, V>;
     constexpr int NF = 3 + (CE_ARR ? 1 : 0) + (CH_ARR ? 1 : 0);     // rows per hand-off
     using Row = typename M::Row;
     constexpr int LV = NT / SPLIT_NW, LAG = LV + 1;
     constexpr int HC = stream_hc(NT);
-    constexpr int SW = 64 * V, OW = SW - 2 * HC;
+    // SD waves side by side (kernels_stream.hpp, strip_x0): LOV lanes per inner side go stale within a tick
+    constexpr int LOV = side_lov(LV, V, SD), UW = 64 - 2 * LOV, U = side_units(LV, V, SD);
+    constexpr int OW = U * V - 2 * HC;
     // only the first wave hides HBM latency (the 5-level form keeps one row in flight instead of two:
     // 8 slots of 12 registers like the 4-level form, 4 waves per SIMD)
     constexpr int PF = ROLE == 0 ? (LV > 4 ? 1 : STREAM_PF) : 0;
     constexpr int S = LV + 2 + PF;              // ring of row slots, tick loop unrolled S times
     const Geom g = p.g;
     const int lane = threadIdx.x & 63;
-    const int x0 = strip_x0<T, NT, V>(p, strip);
+    const int x0 = strip_x0<T, NT, V, SD, LV>(p, strip) + side * (UW * V);      // this wave's window of the strip
     const M m(p, x0, lane);
     const int j0 = m.j0;
-    const bool st_ok = m.ld_ok && j0 >= strip * OW && j0 < (strip + 1) * OW;
+    // lanes whose values survive a tick (all of them with one wave per strip)
+    const bool own = SD == 1 || ((side == 0 || lane >= LOV) && (side == SD - 1 || lane < 64 - LOV));
+    const bool st_ok = m.ld_ok && own && j0 >= strip * OW && j0 < (strip + 1) * OW;
     const size_t col = (size_t)(m.ld_ok ? j0 : 0);
     const int tau0 = ra - NT, tau1 = rb + NT;                    // level-0 rows [tau0, tau1)
     const int tend = rb + LV + (SPLIT_NW - 1) * LAG;              // ticks [tau0, tend) for every wave
@@ -235,7 +239,7 @@ __device__ __forceinline__ void split_body(const PassParams<T> &p, const int str
 #pragma unroll
     for (int l = 1; l <= LV; ++l) first[l] = t0 + l <= p.nlev ? ra - NT + t0 + 2 * l - 1 : (1 << 30);
     // hand-off ring: [hand-off h][slot d][field][lane]
-    auto buf = [&](int h, int d, int field) { return lds + ((h * HAND_DEPTH + d) * NF + field) * 64 + lane; };
+    auto buf = [&](int h, int d, int field) { return lds + ((h * HAND_DEPTH + d) * NF + field) * U + side * UW + lane; };
 
 #ifdef FDTD2D_TRACE
     unsigned long long trace_bar = 0;       // cycles this wave waits at the tick barrier (profiling build)
@@ -339,11 +343,13 @@ __device__ __forceinline__ void split_body(const PassParams<T> &p, const int str
                 }
             } else {
                 const int d = tau & 1;
-                *buf(w, d, 0) = f.e;
-                *buf(w, d, 1) = f.x;
-                *buf(w, d, 2) = f.y;
-                if (CE_ARR) *buf(w, d, 3) = f.ce;
-                if (CH_ARR) *buf(w, d, NF - 1) = f.ch;
+                if (own) {          // (neighbouring windows overlap: each lane of the joint row has ONE writer)
+                    *buf(w, d, 0) = f.e;
+                    *buf(w, d, 1) = f.x;
+                    *buf(w, d, 2) = f.y;
+                    if (CE_ARR) *buf(w, d, 3) = f.ce;
+                    if (CH_ARR) *buf(w, d, NF - 1) = f.ch;
+                }
             }
 #ifdef FDTD2D_TRACE
             const unsigned long long tb0 = __builtin_amdgcn_s_memtime();
@@ -355,24 +361,28 @@ __device__ __forceinline__ void split_body(const PassParams<T> &p, const int str
         }
     }
 #ifdef FDTD2D_TRACE
-    if (p.trace && lane == 0 && w < 4) p.trace[8 * (size_t)blockIdx.x + 4 + w] = trace_bar;
+    if (p.trace && lane == 0 && w < 4 && side == 0) p.trace[8 * (size_t)blockIdx.x + 4 + w] = trace_bar;
 #endif
 }
 
 // FUSE: the zone tiles are the first workgroups of the launch and share its LDS allocation (a
 // workgroup is either a tile or a strip).  That saves the side-stream k_zone launch and its two
 // cross-stream event waits per pass; the build without the zone code serves zone_split = 1.
-template <class T, int NT, int SPLIT_NW, bool FUSE, bool CE_ARR = false, bool CH_ARR = false, int V = Vec<T>::N>
-__global__ __launch_bounds__(64 * SPLIT_NW) void k_bulk_split(const PassParams<T> p)
+template <class T, int NT, int SPLIT_NW, bool FUSE, bool CE_ARR = false, bool CH_ARR = false, int V = Vec<T>::N, int SD = 1>
+__global__ __launch_bounds__(64 * SPLIT_NW * SD) void k_bulk_split(const PassParams<T> p)
 {
     static_assert(NT % SPLIT_NW == 0, "levels must divide evenly over the waves");
-    constexpr int SW = 64 * V;
+    static_assert(SD == 1 || !FUSE, "strips of several waves side by side take their zone tiles from k_zone");
+    constexpr int SW = 64 * V, LV = NT / SPLIT_NW;
     constexpr int NF = 3 + (CE_ARR ? 1 : 0) + (CH_ARR ? 1 : 0);
     // one LDS allocation, used either as the hand-off buffers of a strip or as a zone tile
-    constexpr int HAND = (SPLIT_NW - 1) * HAND_DEPTH * NF * 64;                         // VecN units
+    constexpr int HAND = (SPLIT_NW - 1) * HAND_DEPTH * NF * side_units(LV, V, SD);      // VecN units
     constexpr int ZONE = !FUSE ? 0 : (ZoneDims<NT>::LDS_ELEMS * (int)sizeof(T) + (int)sizeof(VecN<T, V>) - 1) /
                                          (int)sizeof(VecN<T, V>);
-    __shared__ VecN<T, V> lds[HAND > ZONE ? HAND : ZONE];
+    // (several waves side by side: the joint rows can exceed the 64 KB a static allocation may have)
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
+    __shared__ VecN<T, V> lds_static[SD > 1 ? 1 : (HAND > ZONE ? HAND : ZONE)];
+    VecN<T, V> *const lds = SD > 1 ? reinterpret_cast<VecN<T, V> *>(lds_dyn) : lds_static;
     int b = blockIdx.x;
 #ifdef FDTD2D_TRACE
     TraceScope trace(p.trace);
@@ -389,8 +399,11 @@ __global__ __launch_bounds__(64 * SPLIT_NW) void k_bulk_split(const PassParams<T
     }
     int strip, ra, rb;
     if (!strip_of_block(p, b, &strip, &ra, &rb)) return;
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int x0 = strip_x0<T, NT, V>(p, strip);
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int w = SD == 1 ? wid : wid % SPLIT_NW, side = SD == 1 ? 0 : wid / SPLIT_NW;
+    // the columns of THIS wave's window decide which body it runs: only the waves at the grid's edges and on the
+    // source columns take the general one
+    const int x0 = strip_x0<T, NT, V, SD, LV>(p, strip) + side * ((64 - 2 * side_lov(LV, V, SD)) * V);
     const bool edge = x0 < 5 || x0 + SW > p.g.C - 5;
     const bool src = p.src_row1 > ra - 2 * NT && p.src_row < rb + NT && p.src_col1 > x0 &&
                      p.src_col < x0 + SW;
@@ -398,18 +411,18 @@ __global__ __launch_bounds__(64 * SPLIT_NW) void k_bulk_split(const PassParams<T
     trace.kind = (edge || src) ? 1 : 2;
 #endif
     // zero the hand-off buffers: the first ticks read rows nobody has written yet
-    for (int n = threadIdx.x; n < HAND; n += 64 * SPLIT_NW)
+    for (int n = threadIdx.x; n < HAND; n += 64 * SPLIT_NW * SD)
 #pragma unroll
         for (int v = 0; v < V; ++v) lds[n].v[v] = T(0);
     __syncthreads();
     if (edge || src) {
-        if (w == 0) split_body<T, NT, SPLIT_NW, CE_ARR, CH_ARR, true, 0, V>(p, strip, ra, rb, w, lds);
-        else if (w == SPLIT_NW - 1) split_body<T, NT, SPLIT_NW, CE_ARR, CH_ARR, true, 2, V>(p, strip, ra, rb, w, lds);
-        else split_body<T, NT, SPLIT_NW, CE_ARR, CH_ARR, true, 1, V>(p, strip, ra, rb, w, lds);
+        if (w == 0) split_body<T, NT, SPLIT_NW, CE_ARR, CH_ARR, true, 0, V, SD>(p, strip, ra, rb, w, side, lds);
+        else if (w == SPLIT_NW - 1) split_body<T, NT, SPLIT_NW, CE_ARR, CH_ARR, true, 2, V, SD>(p, strip, ra, rb, w, side, lds);
+        else split_body<T, NT, SPLIT_NW, CE_ARR, CH_ARR, true, 1, V, SD>(p, strip, ra, rb, w, side, lds);
     } else {
-        if (w == 0) split_body<T, NT, SPLIT_NW, CE_ARR, CH_ARR, false, 0, V>(p, strip, ra, rb, w, lds);
-        else if (w == SPLIT_NW - 1) split_body<T, NT, SPLIT_NW, CE_ARR, CH_ARR, false, 2, V>(p, strip, ra, rb, w, lds);
-        else split_body<T, NT, SPLIT_NW, CE_ARR, CH_ARR, false, 1, V>(p, strip, ra, rb, w, lds);
+        if (w == 0) split_body<T, NT, SPLIT_NW, CE_ARR, CH_ARR, false, 0, V, SD>(p, strip, ra, rb, w, side, lds);
+        else if (w == SPLIT_NW - 1) split_body<T, NT, SPLIT_NW, CE_ARR, CH_ARR, false, 2, V, SD>(p, strip, ra, rb, w, side, lds);
+        else split_body<T, NT, SPLIT_NW, CE_ARR, CH_ARR, false, 1, V, SD>(p, strip, ra, rb, w, side, lds);
     }
 }
 

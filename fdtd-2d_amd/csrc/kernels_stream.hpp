@@ -152,12 +152,22 @@ __device__ __forceinline__ double from_prev(double x)
 // inside the right Mur band a cell depends on columns j-2..j of the previous level, so
 // invalid data entering from a strip's left edge would advance two columns per level
 // there; with the shift that edge is a full strip width away from the band.
-template <class T, int NT, int V = Vec<T>::N>
+//
+// SD > 1 (level-split kernel only): SD waves side by side share a strip.  Within a tick a wave advances LV levels,
+// so its values within LV columns of its window's INNER edges go stale -- LOV = ceil(LV / V) lanes per side.  The
+// windows of neighbouring waves therefore overlap by 2 LOV lanes, each wave hands on only the lanes it still owns,
+// and the next level group reads full 64-lane windows out of the joint row in LDS: the waves exchange their boundary
+// columns through the hand-off they perform anyway.  Only the strip's two OUTER edges pay the HC = NT columns of
+// overlap: 32 of 504 columns (SD = 2) or of 1000 (SD = 4) instead of 32 of 256.
+constexpr int side_lov(int lv, int v, int sd) { return sd > 1 ? (lv + v - 1) / v : 0; }
+constexpr int side_units(int lv, int v, int sd) { return sd * 64 - (sd - 1) * 2 * side_lov(lv, v, sd); }   // lanes of a joint row
+constexpr int strip_width(int lv, int v, int sd) { return side_units(lv, v, sd) * v; }                      // columns held
+template <class T, int NT, int V = Vec<T>::N, int SD = 1, int LV = 4>
 __device__ __forceinline__ int strip_x0(const PassParams<T> &p, int strip)
 {
-    constexpr int SW = 64 * V, HC = stream_hc(NT), OW = SW - 2 * HC;
+    constexpr int WT = strip_width(LV, V, SD), HC = stream_hc(NT), OW = WT - 2 * HC;
     int x0 = strip * OW - HC;
-    if (strip == p.nstrips - 1) x0 = min(x0, (p.g.C - SW + 3) & ~3);
+    if (strip == p.nstrips - 1) x0 = min(x0, (p.g.C - WT + 3) & ~3);
     return x0;
 }
 

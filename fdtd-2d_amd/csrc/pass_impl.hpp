@@ -5,10 +5,17 @@
 
 namespace fdtd_host {
 
+// geometry of the strips of a pass: columns held, columns written
+inline int pass_strip_ow(int nt, int v, int nw, int sd)
+{
+    return fdtd::strip_width(nt / nw, v, sd) - 2 * fdtd::stream_hc(nt);
+}
+
 template <class T, int NT, bool CE_ARR, bool CH_ARR, int V = fdtd::Vec<T>::N>
 int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
 {
     using D = fdtd::ZoneDims<NT>;
+    const int sd = h->shape_now.side > 1 ? h->shape_now.side : 1;
     const int region = std::max(0, p.band_hi - p.band_lo);
     p.nbands = (region + p.band_rows - 1) / p.band_rows;
     p.nbands_e = (region + p.band_rows_e - 1) / p.band_rows_e;
@@ -18,7 +25,7 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
     p.band_rows_s = std::max(16, std::min(p.band_rows_e, p.band_rows / 3));
     p.nbands_s = (region + p.band_rows_s - 1) / p.band_rows_s;
     if (p.src_col1 > p.src_col && p.band_rows_s < p.band_rows && p.nstrips > 2) {
-        constexpr int SWc = 64 * V, OWc = SWc - 2 * fdtd::stream_hc(NT);
+        const int SWc = sd > 1 ? fdtd::strip_width(NT / 4, V, sd) : 64 * V, OWc = SWc - 2 * fdtd::stream_hc(NT);
         int s0 = -1, s1 = -1;
         for (int st = 1; st <= p.nstrips - 2; ++st) {
             const int x0 = st * OWc - fdtd::stream_hc(NT);
@@ -40,10 +47,11 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
     const long long zones = (long long)(p.zone_top + p.zone_bot) * p.zone_tiles;
     p.xcd_map = 0;
     p.main_pad = p.main_per = p.main_tasks = p.n_inner = 0;
-    if (h->xcd_map && NT >= 8 && h->use_level_split(NT, p.band_lo, p.band_hi) && p.nstrips - 2 - p.n_src > 0) {
+    const bool xcd = h->xcd_map >= 0 ? h->xcd_map != 0 : h->shape_now.xcd != 0;
+    if (xcd && NT >= 8 && h->use_level_split(NT, p.band_lo, p.band_hi) && p.nstrips - 2 - p.n_src > 0) {
         // (the zone tiles ride in front of the bulk when fused: the pad makes the first inner-strip task a multiple
         // of 8 in the index the hardware sees)
-        const bool side = zones > 0 && (h->zone_split == 1 || NT > 16);
+        const bool side = zones > 0 && (h->zone_split == 1 || NT > 16 || sd > 1);
         const long long front = (side ? 0 : zones) + 2LL * p.nbands_e + (long long)p.n_src * p.nbands_s;
         p.xcd_map = 1;
         p.n_inner = p.nstrips - 2 - p.n_src;
@@ -61,7 +69,7 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
             // k_zone on the side stream (zone_split = 1)
             // (20-step passes: 4 waves x 5 levels at 4 workgroups per CU; a fused 46-row zone tile would
             // take 48 KB of LDS from every workgroup and leave 3, so their zones always run as k_zone)
-            const bool side = zones > 0 && (h->zone_split == 1 || NT > 16);
+            const bool side = zones > 0 && (h->zone_split == 1 || NT > 16 || sd > 1);
             p.fused_zones = zones > 0 && !side;
             if (side) {
                 HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
@@ -97,7 +105,28 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
                 // (array materials: one more row per slot and hand-off for each coefficient array)
                 const int nw = h->split_waves_for(NT, p.band_lo, p.band_hi);
                 const dim3 grid((unsigned)blocks), wg(64 * nw);
-                if constexpr (NT > 16) {
+                if (sd > 1) {
+                    // SD waves side by side per level group (4 waves x NT / 4 levels each): 64 * 4 * SD threads, the
+                    // joint hand-off rows in dynamic LDS
+                    if constexpr (sizeof(T) == 4 && (NT == 16 || NT == 20)) {
+                        constexpr int NFc = 3 + (CE_ARR ? 1 : 0) + (CH_ARR ? 1 : 0);
+                        auto go = [&](auto sdc) -> int {
+                            constexpr int SDc = decltype(sdc)::value;
+                            constexpr size_t dyn = (size_t)3 * fdtd::HAND_DEPTH * NFc * fdtd::side_units(NT / 4, V, SDc) * sizeof(fdtd::VecN<T, V>);
+                            auto kern = &fdtd::k_bulk_split<T, NT, 4, false, CE_ARR, CH_ARR, V, SDc>;
+                            HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+                            hipLaunchKernelGGL(kern, grid, dim3(64 * 4 * SDc), dyn, h->stream, p);
+                            return 0;
+                        };
+                        int rc2;
+                        if (sd == 2) rc2 = go(std::integral_constant<int, 2>{});
+                        else if constexpr (!CE_ARR && !CH_ARR) rc2 = go(std::integral_constant<int, 4>{});
+                        else return fail(h, FDTD2D_E_ARG, "4 waves side by side: uniform materials only");
+                        if (rc2) return rc2;
+                    } else {
+                        return fail(h, FDTD2D_E_ARG, "strips of several waves side by side: float32 16- and 20-step passes only");
+                    }
+                } else if constexpr (NT > 16) {
                     // 20 steps: 4 waves x 5 levels, zone tiles on the side stream
                     hipLaunchKernelGGL((fdtd::k_bulk_split<T, NT, 4, false, CE_ARR, CH_ARR, V>), grid, wg, 0, h->stream, p);
                 } else {
@@ -201,7 +230,6 @@ template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, 
     // (k_bulk also instantiates with 2 columns per lane -- 86 VGPRs, 4-5 waves per SIMD -- but
     // that measured 20 % slower than 4 columns: profiles/r01_kpass_ablation.txt)
     constexpr int V = fdtd::Vec<T>::N;
-    const int OW = 64 * V - 2 * fdtd::stream_hc(nt);
     fdtd::PassParams<T> p;
     p.ez_in = (const T *)h->ez[h->cur];
     p.hx_in = (const T *)h->hxb[h->hcur];
@@ -217,7 +245,6 @@ template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, 
     p.g = h->geom();
     p.band_lo = band_lo;
     p.band_hi = band_hi;
-    p.nstrips = (h->cols + OW - 1) / OW;
     int br = h->stream_band_rows;
     h->shape_now = fdtd2d::Shape{0, 0};
     if (const fdtd2d::Shape *gs = br <= 0 ? h->shape_given(nt) : nullptr) {
@@ -230,6 +257,17 @@ template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, 
             h->shape_now = it->second;
             br = it->second.band_rows;
         }
+    }
+    // waves side by side per level group (strips 2 or 4 waves wide): the caller's option, else the shape's
+    {
+        int sd = h->side_waves > 0 ? h->side_waves : std::max(1, h->shape_now.side);
+        if (!h->side_ok(nt, sd) || !h->use_level_split(nt, band_lo, band_hi) || h->pml_split(nt) ||
+            (h->split_waves != 0 && h->split_waves != 4))
+            sd = 1;
+        h->shape_now.side = sd;
+        if (sd > 1) h->shape_now.waves = 4;
+        const int OW = pass_strip_ow(nt, V, 4, sd);
+        p.nstrips = (h->cols + OW - 1) / OW;
     }
     if (br <= 0) {
         // Measured on MI355X (interleaved A/B, profiles/r01_band_sweep.txt): the pass is fastest
@@ -258,7 +296,8 @@ template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, 
     h->last_nt = nt;
     h->shape_last = fdtd2d::Shape{p.band_rows,
                                   h->pml_split(nt) ? 4 : (h->use_level_split(nt, band_lo, band_hi) ? h->split_waves_for(nt, band_lo, band_hi) : 1),
-                                  h->pml_split(nt) ? (h->shape_now.edge_rows > 0 ? h->shape_now.edge_rows : h->pml_layer_rows) : p.band_rows_e};
+                                  h->pml_split(nt) ? (h->shape_now.edge_rows > 0 ? h->shape_now.edge_rows : h->pml_layer_rows) : p.band_rows_e,
+                                  h->shape_now.side, h->xcd_map >= 0 ? h->xcd_map : h->shape_now.xcd};
     p.zone_top = ztop;
     p.zone_bot = zbot;
     p.trash = (T *)h->trash;

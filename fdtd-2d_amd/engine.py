@@ -294,7 +294,7 @@ class Engine:
         return self
 
     def set_option(self, max_pass_steps=None, band_rows=None, zone_split=None, level_split=None,
-                   split_waves=None, autotune=None, long_shape=None, xcd_map=None):
+                   split_waves=None, autotune=None, long_shape=None, xcd_map=None, side_waves=None):
         """Speed knobs of run(): longest temporally blocked pass (0 = single-step kernels
         only) and rows per streaming band.  Results do not depend on them."""
         if max_pass_steps is not None:
@@ -309,13 +309,16 @@ class Engine:
             self._ck(self._lib.fdtd2d_set_option(self._h, _abi.OPT_AUTOTUNE, int(bool(autotune))))
         if split_waves is not None:
             self._ck(self._lib.fdtd2d_set_option(self._h, _abi.OPT_SPLIT_WAVES, int(split_waves)))
+        if side_waves is not None:
+            self._ck(self._lib.fdtd2d_set_option(self._h, _abi.OPT_SIDE_WAVES, int(side_waves)))
         if xcd_map is not None:
             self._ck(self._lib.fdtd2d_set_option(self._h, _abi.OPT_XCD_MAP, int(xcd_map)))
-        if long_shape is not None:       # (band rows, waves per strip[, edge band rows[, pass length]]); pass
-            br, nw, *er = long_shape     # length 0 / absent = the full-length passes
+        if long_shape is not None:       # (band rows, waves per strip[, edge band rows[, pass length[, waves side by
+            br, nw, *er = long_shape     # side[, xcd map]]]]); pass length 0 / absent = the full-length passes
+            er = list(er) + [0] * (4 - len(er))
             self._ck(self._lib.fdtd2d_set_option(self._h, _abi.OPT_LONG_SHAPE,
-                                                 int(br) + 65536 * int(nw) + (int(er[0]) << 32 if er else 0)
-                                                 + (int(er[1]) << 48 if len(er) > 1 else 0)))
+                                                 int(br) + 65536 * int(nw) + (int(er[0]) << 32) + (int(er[1]) << 48)
+                                                 + (int(er[2]) << 56) + (int(er[3]) << 59)))
         return self
 
     def sync(self):
@@ -416,6 +419,12 @@ class Engine:
         self._ck(self._lib.fdtd2d_reduce(self._h, f, C.byref(s), C.byref(m)))
         return float(s.value), float(m.value)
 
+    def measure_copy(self, reps=4) -> float:
+        """GB/s (read + written) of a plain copy of the three field arrays on this device, now."""
+        v = C.c_double()
+        self._ck(self._lib.fdtd2d_measure_copy(self._h, int(reps), C.byref(v)))
+        return float(v.value)
+
     def clock_probe_start(self, micros):
         """Start the shader-clock probe (runs for `micros` us beside whatever is launched next)."""
         self._ck(self._lib.fdtd2d_clock_probe_start(self._h, int(micros)))
@@ -442,8 +451,10 @@ class Engine:
 
     @property
     def last_shape(self):
-        """(band rows, waves per strip, band rows of the first / last strip) of the last pass."""
-        return self.info(_abi.INFO_LAST_BAND_ROWS), self.info(_abi.INFO_LAST_WAVES), self.info(_abi.INFO_LAST_EDGE_ROWS)
+        """(band rows, waves per level group, band rows of the first / last strip, waves side by side, xcd map) of the
+        last pass."""
+        return (self.info(_abi.INFO_LAST_BAND_ROWS), self.info(_abi.INFO_LAST_WAVES), self.info(_abi.INFO_LAST_EDGE_ROWS),
+                self.info(_abi.INFO_LAST_SIDE_WAVES), self.info(_abi.INFO_LAST_XCD_MAP))
 
     @property
     def last_pass_steps(self) -> int:

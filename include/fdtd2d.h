@@ -84,6 +84,8 @@ typedef struct fdtd2d fdtd2d_t;
 #define FDTD2D_INFO_LAST_WAVES    20 /* its waves per (band, strip): 1 (k_bulk), 4 or 8 (k_bulk_split) */
 #define FDTD2D_INFO_LAST_EDGE_ROWS 21 /* its band height on the first / last strip */
 #define FDTD2D_INFO_LAST_PASS_STEPS 22 /* the kernel length (1, 2, 4, 8, 16, 20) of the last pass; 0: none yet */
+#define FDTD2D_INFO_LAST_SIDE_WAVES 23 /* its waves side by side per level group (strip width 256, 504 or 1000 columns) */
+#define FDTD2D_INFO_LAST_XCD_MAP    24 /* 1 if its tasks were dealt out XCD by XCD */
 #define FDTD2D_INFO_CYCLE_STEPS   18 /* longest pass the current configuration runs: 16 (float32, Mur
                                          frame, >= 12 Mi cells per GPU), else 8, 0 if passes are off */
 
@@ -244,13 +246,19 @@ int fdtd2d_sync(fdtd2d_t *h);
 #define FDTD2D_OPT_LONG_SHAPE      6   /* launch shape of the passes of one length, value = band rows + 2^16 *
                                          waves per strip (0 = automatic) + 2^32 * band rows of the first /
                                          last strip (0 = the same) + 2^48 * pass length (0 = the full-length
-                                         passes, 16 or 8 steps; 20 = the 20-step remainder pass): re-use a
-                                         shape the tuner found in another process; band rows 0 clears it */
+                                         passes, 16 or 8 steps; 20 = the 20-step remainder pass) + 2^56 * waves
+                                         side by side (0 = 1) + 2^59 * xcd map: re-use a shape the tuner found
+                                         in another process; band rows 0 clears it */
 #define FDTD2D_OPT_XCD_MAP         7   /* task order of the level-split pass: 1 = every XCD (workgroups b, b + 8, ...
                                          under the round-robin placement the hardware is observed to use) gets a
                                          contiguous run of (band, strip) tasks with the strips of one band next to
                                          each other, so that the cache lines neighbouring strips share are fetched
-                                         once per XCD L2; 0 = all bands of one strip consecutive.  Speed only. */
+                                         once per XCD L2; 0 = all bands of one strip consecutive; -1 (default) = the
+                                         launch-shape tuner decides per shape.  Speed only. */
+#define FDTD2D_OPT_SIDE_WAVES      8   /* float32 16- / 20-step passes: 2 or 4 waves side by side per level group share a
+                                         strip of 504 / 1000 columns and exchange their boundary columns through the
+                                         LDS hand-off -- the 32 overlap columns of a strip are paid once per 504 / 1000
+                                         columns instead of per 256; 1 = never; 0 (default) = the tuner decides. */
 int fdtd2d_set_option(fdtd2d_t *h, int option, long long value);
 
 /* ---- row-slab halo exchange (transport is the caller's: RCCL via torch.distributed) -- */
@@ -337,6 +345,10 @@ int fdtd2d_time_launches(fdtd2d_t *h, int nlaunch, int steps_each, float *ms);
  * the constant 100 MHz counter (s_memrealtime) at both ends; launch the work to be observed right after it.
  * _read waits for them and returns the clock in MHz per XCC id (0 where no probe landed).  Measurement aid. */
 int fdtd2d_clock_probe_start(fdtd2d_t *h, int micros);
+/* What a plain copy reaches on this device right now: copies the three current field arrays into the other buffer set
+ * (which the next pass overwrites anyway) `reps` times with a 16-byte-per-lane grid-stride kernel and returns
+ * (bytes read + bytes written) / time in GB/s.  The yardstick beside the 8 TB/s of the data sheet.  Synchronous. */
+int fdtd2d_measure_copy(fdtd2d_t *h, int reps, double *gbps);
 int fdtd2d_clock_probe_read(fdtd2d_t *h, double *mhz8);
 
 int fdtd2d_bytes_per_cell_step(const fdtd2d_t *h);

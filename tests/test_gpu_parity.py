@@ -862,3 +862,34 @@ def test_16_step_passes_match_oracle(fd, onp, shape, src, split_waves):
         assert eng.info(16) == 3
     for a, b, k in zip(got, ref, ("Ez", "Hx", "Hy")):
         assert np.array_equal(a, b), f"{k} {shape} src={src}: {np.argwhere(a != b)[:4]}"
+
+
+@pytest.mark.parametrize("kind", ["uniform", "eps", "eps+mu"])
+@pytest.mark.parametrize("side,shape,src", [(2, (150, 4200), (24, 251)), (2, (131, 4096), (60, 4095)), (4, (140, 8300), (0, 0)),
+                                            (4, (150, 8192), (70, 1003)), (2, (300, 5000), (150, 1500))])
+@pytest.mark.parametrize("xcd", [0, 1])
+def test_strips_of_several_waves_side_by_side_match_oracle(fd, onp, side, shape, src, kind, xcd):
+    """FDTD2D_OPT_SIDE_WAVES = 2 / 4: strips 504 / 1000 columns wide, whose 2 / 4 waves per level group exchange their
+    boundary columns through the LDS hand-off (kernels_stream.hpp, strip_x0), with both task orders
+    (FDTD2D_OPT_XCD_MAP).  36 steps = a 16-step pass + a 20-step pass (4 levels and 5 levels per wave: 1 and 2 lanes
+    of window overlap), float32, from a random state; sources on a window seam, on the last column, in the corner, on
+    a strip seam.  Value-identical to the oracle."""
+    r, c = shape
+    if side == 4 and kind != "uniform":
+        pytest.skip("4 waves side by side (1024 threads, 128 VGPRs each) exist for uniform materials only")
+    rng = np.random.default_rng(r * c + side)
+    Ez, Hx, Hy, eps, mu = _random_state(rng, r, c, np.float32, onp, vary_mu=(kind == "eps+mu"))
+    if kind == "uniform":
+        eps = np.full((r, c), 2.3 * onp.EPS0, np.float32)
+    n = 36
+    amps = rng.standard_normal(n)
+    ref = [a.copy() for a in (Ez, Hx, Hy)]
+    onp.leapfrog(*ref, eps, mu, DT, DX, n, src[0], src[1], amps=amps)
+    with fd.Engine(r, c, DT, DX, dtype=np.float32) as eng:
+        eng.set_materials(eps, mu).set_option(max_pass_steps=20, band_rows=40, side_waves=side, xcd_map=xcd)
+        eng.upload(Ez, Hx, Hy)
+        eng.run(n, src[0], src[1], amps)
+        got = eng.download()
+        assert eng.info(16) == 2 and eng.last_shape[3] == side and eng.last_shape[4] == xcd and eng.last_pass_steps == 20
+    for a, b, k in zip(got, ref, ("Ez", "Hx", "Hy")):
+        assert np.array_equal(a, b), f"{k} side={side} {kind}: {np.argwhere(a != b)[:4]}"

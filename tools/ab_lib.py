@@ -22,7 +22,7 @@ eng = bench.make_engine(fd, g, g, mat, 0, "mur")
 cyc = eng.cycle_steps
 eng.prepare(cyc * 4); eng.run(cyc * 4).sync()
 ms = np.sort(eng.time_launches(24, cyc))
-print(json.dumps({"us": float(np.median(ms) * 1e3), "min": float(ms[0] * 1e3), "shape": [eng.info(19), eng.info(20)], "cyc": cyc}))
+print(json.dumps({"us": float(np.median(ms) * 1e3), "min": float(ms[0] * 1e3), "shape": list(eng.last_shape), "cyc": cyc}))
 ''' % (ROOT, ROOT)
 for g in grids:
     for r in range(rounds):

@@ -70,6 +70,8 @@ HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB
 SIMDS, PEAK_GHZ, VALU_ISSUE_CYCLES = 1024, 2.4, 2.0      # 256 CUs x 4 SIMD-32; wave64 VALU = 2 cycles
 SLAB_ROWS = 4096
 NP_DTYPE = {"f32": np.float32, "f64": np.float64}
+SHAPE_KEYS = ("band_rows", "waves_per_level_group", "edge_strip_band_rows", "waves_side_by_side", "xcd_map",
+              "filler_band_rows", "filler_bands_per_strip")
 ENGINE_OPTS = {}     # --opt name=value: Engine.set_option() knobs for A/B experiments (speed only, same results)
 
 
@@ -245,8 +247,7 @@ def make_engine(fd, rows, cols, materials, device, boundary, shapes=None, autotu
         eng.set_option(**ENGINE_OPTS)
     for nt, shp in (shapes or {}).items():       # {pass length: (band rows, waves, edge rows, waves side by side, xcd map)}
         if shp and shp[0]:
-            shp = list(shp) + [0] * (5 - len(shp))
-            eng.set_option(long_shape=(shp[0], shp[1], shp[2], int(nt) if int(nt) != eng.cycle_steps else 0, shp[3], shp[4]))
+            eng.set_shape(shp, int(nt) if int(nt) != eng.cycle_steps else 0)
     return eng
 
 
@@ -463,8 +464,7 @@ def roofline_block(cells, steps, r, traffic):
            "traffic_source": None, "overfetch": None, "valu_frac": None,
            "kernel": None, "kernels": None, "passes_per_run": passes, "steps_per_run": steps,
            "run_event_ms": {"median": round(ev, 5), "min": round(min(r["events_ms"]), 5), "max": round(max(r["events_ms"]), 5)},
-           "launch_shape": dict(zip(("band_rows", "waves_per_level_group", "edge_strip_band_rows", "waves_side_by_side",
-                                     "xcd_map"), r["run_shape"]), pass_steps=r["run_last_nt"]),
+           "launch_shape": dict(zip(SHAPE_KEYS, r["run_shape"]), pass_steps=r["run_last_nt"]),
            "algorithmic": {"bytes_per_cell_step": bpc, "bytes_per_run": int(alg_bytes),
                            "rate_GBps": round(alg_bytes / (ev * 1e-3) / 1e9, 1),
                            "x_peak": round(alg_bytes / (ev * 1e-3) / 1e9 / HBM_PEAK_GBS, 3)}}
@@ -486,8 +486,7 @@ def roofline_block(cells, steps, r, traffic):
         ms, spl = r["launch_ms"], r["launch_steps"]
         ss = {"steps_per_launch": spl, "avg_launch_ms": round(ms, 5), "launch_ms_min_max": [round(v, 5) for v in r["launch_ms_minmax"]],
               "value": round(cells * spl / (ms * 1e-3) / 1e6, 1),
-              "launch_shape": dict(zip(("band_rows", "waves_per_level_group", "edge_strip_band_rows", "waves_side_by_side",
-                                        "xcd_map"), r["full_shape"])),
+              "launch_shape": dict(zip(SHAPE_KEYS, r["full_shape"])),
               "algorithmic_x_peak": round(cells * spl * bpc / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 3)}
         if isinstance(traffic, dict) and "full" in traffic and traffic["cycle"] == spl:
             t = traffic["full"]
@@ -621,7 +620,7 @@ def main():
                     help="fixed launch-shape rules (for profiler runs: the tuner's trial launches would be "
                          "averaged into the per-kernel statistics); combine with --shape")
     ap.add_argument("--shape", action="append",
-                    help="pass length:band rows:waves:edge band rows[:waves side by side:xcd map] (repeatable)")
+                    help="pass length:band rows:waves:edge band rows[:waves side by side:xcd map:filler rows:fillers per strip] (repeatable)")
     ap.add_argument("--opt", action="append", default=[], help="Engine.set_option knob, name=int (repeatable; experiments)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--child-steps", type=int, default=16, help=argparse.SUPPRESS)

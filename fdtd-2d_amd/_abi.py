@@ -24,7 +24,7 @@ BOUNDARY_NONE, BOUNDARY_MUR5, BOUNDARY_PML = 0, 1, 2
 SRC_NONE, SRC_RICKER, SRC_SINUSOIDAL = 0, 1, 2
 FIELD_EZ, FIELD_HX, FIELD_HY = 0, 1, 2
 
-OPT_MAX_PASS_STEPS, OPT_BAND_ROWS, OPT_ZONE_SPLIT, OPT_LEVEL_SPLIT, OPT_SPLIT_WAVES, OPT_AUTOTUNE, OPT_LONG_SHAPE, OPT_XCD_MAP, OPT_SIDE_WAVES = 0, 1, 2, 3, 4, 5, 6, 7, 8
+OPT_MAX_PASS_STEPS, OPT_BAND_ROWS, OPT_ZONE_SPLIT, OPT_LEVEL_SPLIT, OPT_SPLIT_WAVES, OPT_AUTOTUNE, OPT_XCD_MAP, OPT_SIDE_WAVES = 0, 1, 2, 3, 4, 5, 7, 8
 
 E_ARG, E_NODEVICE, E_NOMEM, E_STATE, E_COURANT = -1, -2, -3, -4, -5
 
@@ -66,6 +66,8 @@ SIGNATURES = {
     "fdtd2d_run_waveform": (_i, [_vp, _i, _i, _i, _i, _d, _ll]),
     "fdtd2d_source_amplitude": (_d, [_i, _d, _d]),
     "fdtd2d_set_option": (_i, [_vp, _i, _ll]),
+    "fdtd2d_set_shape": (_i, [_vp, _i, C.POINTER(_i), _i]),
+    "fdtd2d_last_shape": (_i, [_vp, C.POINTER(_i), _i]),
     "fdtd2d_sync": (_i, [_vp]),
     "fdtd2d_halo_bytes": (_ll, [_vp]),
     "fdtd2d_halo_pack": (_i, [_vp, _i, _vp]),

@@ -134,6 +134,10 @@ struct fdtd2d {
                                  // is ~2x slower per row, equal heights make them the tail of a launch
         int side = 1;            // waves side by side per level group (1, 2 or 4; kernels_stream.hpp, strip_x0)
         int xcd = 0;             // 1: tasks dealt out XCD by XCD (FDTD2D_OPT_XCD_MAP), chosen per shape by the tuner
+        // One-round launches (every workgroup resident from the start): the zone tiles are done after a fraction of
+        // the launch and their slots would idle.  The last n_short bands of every inner strip are `short_rows` tall
+        // and come last in launch order: they start in the slots the zone tiles free and end with the tall bands.
+        int short_rows = 0, n_short = 0;
     };
     // strips of several waves side by side exist for the float32 16- and 20-step level-split kernels with 4 waves
     // per level group, on grids wide enough for a few of them
@@ -146,7 +150,7 @@ struct fdtd2d {
     }
     std::map<std::array<int, 3>, Shape> tuned;
     int autotune = 1;            // FDTD2D_OPT_AUTOTUNE
-    // FDTD2D_OPT_LONG_SHAPE: launch shapes given by the caller (measured elsewhere, e.g. by another process), by
+    // fdtd2d_set_shape: launch shapes given by the caller (measured elsewhere, e.g. by another process), by
     // pass length; key 0 = the full-length passes (cycle_steps())
     std::map<int, Shape> given_shape;
     const Shape *shape_given(int nt) const

@@ -994,7 +994,7 @@ static int tune_pass(fdtd2d *h, int nt, int lo, int hi, bool zt, bool zb, int sr
         const int ns = (h->cols + ow - 1) / ow;
         // ZoneDims<NT>::WZ; 20-step passes and strips of several waves take their zones from k_zone beside the bulk
         const int zw = sd > 1 ? 0 : (nt == 16 ? 30 : (nt == 8 ? 14 : 0));
-        const int zones = zw ? ((zt ? 1 : 0) + (zb ? 1 : 0)) * ((h->cols + zw - 1) / zw) : 0;
+        const int zone_tiles = zw ? ((zt ? 1 : 0) + (zb ? 1 : 0)) * ((h->cols + zw - 1) / zw) : 0;
         int n_src = 0;                           // inner strips that hold source columns (bands of their own)
         for (int st = 1; has_src && st <= ns - 2; ++st) {
             const int x0 = st * ow - fdtd::stream_hc(nt);
@@ -1005,6 +1005,10 @@ static int tune_pass(fdtd2d *h, int nt, int lo, int hi, bool zt, bool zb, int sr
             if (nw == 8 && (!both_nw || sd > 1)) continue;
             // resident workgroups (VGPR / LDS limits): 16 waves per CU
             const int slots = 256 * (nw == 8 ? 2 : 4) / sd;
+            // workgroups of the fused zone tiles: float32 16-step passes keep a tile in the registers of two waves
+            // (kernels_zone.hpp), nw / 2 tiles per workgroup; the LDS tiles take a workgroup each
+            const int tpw = (h->dtype == FDTD2D_F32 && nt >= 16) ? nw / 2 : 1;
+            const int zones = (zone_tiles + tpw - 1) / tpw;
             const double fill = 2.0 * nt + nw - 1;
             for (int k : {1, 2, 3, 4}) {
                 for (double w_e : {1.0, 2.0, 3.0}) {            // edge bands as tall, 1/2, 1/3 as long-lived
@@ -1021,6 +1025,28 @@ static int tune_pass(fdtd2d *h, int nt, int lo, int hi, bool zt, bool zb, int sr
                                              w_e == 1.0 ? 0 : std::max(8, (region + ne - 1) / ne), sd};
                     }
                     if (best.band_rows >= 8) cand.push_back(best);
+                }
+                // One round with fused zone tiles: the tiles are done after tz ticks and free their slots.  The last
+                // `nshort` bands of every inner strip are tz rows shorter and come last in launch order: they start in
+                // those slots and end with the tall bands (4096^2: 750 + 274 bulk workgroups instead of 750).
+                const int n_i = std::max(1, ns - 2 - n_src), nshort = zones / n_i;
+                for (int tz : {32, 48, 64, 80, 96, 112}) {
+                    if (k != 1 || zones == 0 || sd != 1 || nshort < 1) break;
+                    for (double w_e : {1.0, 2.0, 3.0}) {
+                        fdtd2d::Shape best{0, 0};
+                        for (int nl = 1; nl <= region / 8; ++nl) {
+                            const int rl = (region + nshort * tz + nl + nshort - 1) / (nl + nshort);     // rows of a tall band
+                            const int rs = rl - tz;
+                            if (rs < 16) break;
+                            const double life = rl + fill, er = life / w_e - fill;
+                            const int ne = w_e == 1.0 ? (region + rl - 1) / rl : (er >= 8 ? (int)std::ceil(region / er) : region / 8);
+                            const int brs = std::max(16, std::min((region + ne - 1) / ne, rl / 3));
+                            const int n_s = n_src * ((region + brs - 1) / brs);
+                            if ((double)n_i * nl + 2.0 * ne + n_s > (double)slots - zones) break;
+                            best = fdtd2d::Shape{rl, both_nw ? nw : 0, w_e == 1.0 ? 0 : std::max(8, (region + ne - 1) / ne), 1, 0, rs, nshort};
+                        }
+                        if (best.band_rows >= 8) cand.push_back(best);
+                    }
                 }
             }
         }
@@ -1100,6 +1126,13 @@ static int tune_pass(fdtd2d *h, int nt, int lo, int hi, bool zt, bool zb, int sr
     std::vector<size_t> order(cand.size());
     for (size_t n = 0; n < order.size(); ++n) order[n] = n;
     std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return best_of[a] < best_of[b]; });
+#ifdef FDTD2D_TUNE_LOG
+    for (size_t k = 0; k < order.size(); ++k) {
+        const fdtd2d::Shape &c = cand[order[k]];
+        fprintf(stderr, "tune nt=%d first rounds #%zu: (%d, %d, %d, side %d, xcd %d, filler %d x %d) %.4f ms\n", nt, k, c.band_rows,
+                c.waves, c.edge_rows, c.side, c.xcd, c.short_rows, c.n_short, best_of[order[k]]);
+    }
+#endif
     // the fastest four go to the finals -- together with their twins whose tasks are dealt out XCD by XCD
     // (FDTD2D_OPT_XCD_MAP: worth 3-5 % on launches of several rounds, -7 % on one-round launches) unless the caller
     // has fixed that choice
@@ -1138,9 +1171,9 @@ static int tune_pass(fdtd2d *h, int nt, int lo, int hi, bool zt, bool zb, int sr
             float ms = 0;
             if ((rc = timed(cand[order[k]], 6, &ms))) break;
 #ifdef FDTD2D_TUNE_LOG      // profiling builds only (tools/): what the tuner saw
-            fprintf(stderr, "tune nt=%d final %d: (%d, %d, %d, side %d, xcd %d) first rounds %.4f ms, now %.4f ms\n", nt, round,
+            fprintf(stderr, "tune nt=%d final %d: (%d, %d, %d, side %d, xcd %d, filler %d x %d) first rounds %.4f ms, now %.4f ms\n", nt, round,
                     cand[order[k]].band_rows, cand[order[k]].waves, cand[order[k]].edge_rows, cand[order[k]].side,
-                    cand[order[k]].xcd, best_of[order[k]], ms);
+                    cand[order[k]].xcd, cand[order[k]].short_rows, cand[order[k]].n_short, best_of[order[k]], ms);
 #endif
             // (8 waves per strip run 5-7 % slower on a run's real fields than in these trials on the fields at
             // hand -- zero in a fresh engine: 8192^2 ring map 0.53 ms in trials, 0.57 ms in the run, while the
@@ -1379,18 +1412,30 @@ int fdtd2d_set_option(fdtd2d_t *h, int option, long long value)
         h->side_waves = (int)value;
         h->tuned.clear();
         return 0;
-    case FDTD2D_OPT_LONG_SHAPE: {
-        const int br = (int)(value & 0xffff), nw = (int)((value >> 16) & 0xffff), er = (int)((value >> 32) & 0xffff);
-        const int nt = (int)((value >> 48) & 0xff);       // 0: the full-length passes
-        const int sd = (int)((value >> 56) & 0x7), xc = (int)((value >> 59) & 0x1);
-        if (value < 0 || (nw != 0 && nw != 4 && nw != 8) || nt > fdtd::STREAM_MAX_NT || (sd != 0 && sd != 1 && sd != 2 && sd != 4))
-            return fail(h, FDTD2D_E_ARG, "shape = band rows + 2^16 * waves (0, 4 or 8) + 2^32 * edge band rows + 2^48 * pass length "
-                                         "+ 2^56 * waves side by side (0, 1, 2, 4) + 2^59 * xcd map");
-        h->given_shape[nt] = fdtd2d::Shape{br, nw, er, sd ? sd : 1, xc};
-        return 0;
-    }
     default: return fail(h, FDTD2D_E_ARG, "unknown option %d", option);
     }
+}
+
+int fdtd2d_set_shape(fdtd2d_t *h, int pass_steps, const int *shape, int n)
+{
+    if (!h || !shape || n < 1) return FDTD2D_E_ARG;
+    int v[FDTD2D_SHAPE_LEN] = {0, 0, 0, 1, 0, 0, 0};
+    for (int k = 0; k < n && k < FDTD2D_SHAPE_LEN; ++k) v[k] = shape[k];
+    if (v[3] == 0) v[3] = 1;
+    if (pass_steps < 0 || pass_steps > fdtd::STREAM_MAX_NT || v[0] < 0 || (v[1] != 0 && v[1] != 4 && v[1] != 8) || v[2] < 0 ||
+        (v[3] != 1 && v[3] != 2 && v[3] != 4) || (v[4] != 0 && v[4] != 1) || v[5] < 0 || v[6] < 0)
+        return fail(h, FDTD2D_E_ARG, "shape = {band rows, waves 0|4|8, edge band rows, side 1|2|4, xcd 0|1, filler rows, fillers per strip}");
+    h->given_shape[pass_steps] = fdtd2d::Shape{v[0], v[1], v[2], v[3], v[4], v[5], v[6]};
+    return 0;
+}
+
+int fdtd2d_last_shape(const fdtd2d_t *h, int *shape, int n)
+{
+    if (!h || !shape || n < 1) return FDTD2D_E_ARG;
+    const fdtd2d::Shape &s = h->shape_last;
+    const int v[FDTD2D_SHAPE_LEN] = {s.band_rows, s.waves, s.edge_rows, s.side, s.xcd, s.short_rows, s.n_short};
+    for (int k = 0; k < n; ++k) shape[k] = k < FDTD2D_SHAPE_LEN ? v[k] : 0;
+    return 0;
 }
 
 int fdtd2d_sync(fdtd2d_t *h)

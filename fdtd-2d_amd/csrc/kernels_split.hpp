@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include "kernels_stream.hpp"
+#include "kernels_zone.hpp"
 
 namespace fdtd {
 
@@ -377,8 +378,8 @@ __global__ __launch_bounds__(64 * SPLIT_NW * SD) void k_bulk_split(const PassPar
     constexpr int NF = 3 + (CE_ARR ? 1 : 0) + (CH_ARR ? 1 : 0);
     // one LDS allocation, used either as the hand-off buffers of a strip or as a zone tile
     constexpr int HAND = (SPLIT_NW - 1) * HAND_DEPTH * NF * side_units(LV, V, SD);      // VecN units
-    constexpr int ZONE = !FUSE ? 0 : (ZoneDims<NT>::LDS_ELEMS * (int)sizeof(T) + (int)sizeof(VecN<T, V>) - 1) /
-                                         (int)sizeof(VecN<T, V>);
+    constexpr int ZONE_ELEMS = zone_in_registers<T, NT>() ? zone_tiles_per_wg<64 * SPLIT_NW>() * 128 : ZoneDims<NT>::LDS_ELEMS;
+    constexpr int ZONE = !FUSE ? 0 : (ZONE_ELEMS * (int)sizeof(T) + (int)sizeof(VecN<T, V>) - 1) / (int)sizeof(VecN<T, V>);
     // (several waves side by side: the joint rows can exceed the 64 KB a static allocation may have)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
     __shared__ VecN<T, V> lds_static[SD > 1 ? 1 : (HAND > ZONE ? HAND : ZONE)];
@@ -388,11 +389,15 @@ __global__ __launch_bounds__(64 * SPLIT_NW * SD) void k_bulk_split(const PassPar
     TraceScope trace(p.trace);
 #endif
     if constexpr (FUSE) {    // zone tiles are the first workgroups of the launch (all NW waves per tile)
-        const int nzone = (p.zone_top + p.zone_bot) * p.zone_tiles;
+        const int nzone = p.zone_wgs;
         if (b < nzone) {
-            const int z = b / p.zone_tiles;
-            zone_body<T, NT, CE_ARR, CH_ARR, 64 * SPLIT_NW>(p, b - z * p.zone_tiles, p.zone_top ? z == 1 : true,
-                                                            reinterpret_cast<T *>(lds));
+            if constexpr (zone_in_registers<T, NT>()) {      // two waves per tile, rows in registers (kernels_zone.hpp)
+                zone_wave_group<T, NT, CE_ARR, CH_ARR, 64 * SPLIT_NW>(p, b, reinterpret_cast<T *>(lds));
+            } else {
+                const int z = b / p.zone_tiles;
+                zone_body<T, NT, CE_ARR, CH_ARR, 64 * SPLIT_NW>(p, b - z * p.zone_tiles, p.zone_top ? z == 1 : true,
+                                                                reinterpret_cast<T *>(lds));
+            }
             return;
         }
         b -= nzone;

@@ -60,8 +60,12 @@ template <class T> struct PassParams {
                                // the launch alone, so these strips get short bands of their own (n_src = 0: none)
     int xcd_map;               // 1: the inner strips' tasks are dealt out XCD by XCD (FDTD2D_OPT_XCD_MAP)
     int main_pad, main_per, main_tasks, n_inner;   // (with xcd_map) empty blocks in front of them, tasks per XCD, tasks, strips
+    int band_rows2, nbands2, split_row;   // "filler" bands: the rows [split_row, band_hi) of the inner strips in nbands2
+                               // shorter bands of band_rows2 rows, LAST in launch order (one-round launches: they start in
+                               // the slots the zone tiles free; nbands2 = 0: none, split_row = band_hi)
     int zone_top, zone_bot;    // 1 if this launch owns the grid's top / bottom zone
     int zone_tiles;            // column tiles per zone
+    int zone_wgs;              // workgroups of the zone part of a fused launch (register-resident tiles: several per workgroup)
     int fused_zones;           // 1: the zone tiles are the first workgroups of the k_bulk launch
                                // (one wave each); 0: k_zone runs them on a side stream
     T *trash;                  // >= 3 x 1 KiB of device scratch: where masked-off stores land
@@ -200,15 +204,25 @@ __device__ __forceinline__ bool strip_of_block(const PassParams<T> &p, int b, in
             if (q >= p.main_per || t >= p.main_tasks) return false;
             band = t / p.n_inner;
             sidx = t - band * p.n_inner;
-        } else {
+        } else if (b < p.n_inner * p.nbands || p.nbands2 == 0) {
             sidx = b / p.nbands;
             band = b - sidx * p.nbands;
+        } else {                        // the filler bands of the inner strips
+            b -= p.n_inner * p.nbands;
+            sidx = b / p.nbands2;
+            band = b - sidx * p.nbands2;
+            int st = sidx + p.strip_first;
+            if (p.n_src > 0 && st >= p.src_strip) st += p.n_src;
+            *strip = st;
+            *ra = p.split_row + band * p.band_rows2;
+            *rb = min(*ra + p.band_rows2, p.band_hi);
+            return *ra < *rb;
         }
         int st = sidx + p.strip_first;
         if (p.n_src > 0 && st >= p.src_strip) st += p.n_src;      // the source strips were dealt with above
         *strip = st;
         *ra = p.band_lo + band * p.band_rows;
-        *rb = min(*ra + p.band_rows, p.band_hi);
+        *rb = min(*ra + p.band_rows, p.split_row);
     }
     return *ra < *rb;
 }
@@ -578,20 +592,6 @@ void k_bulk(const PassParams<T> p)
         stream_body<T, NT, CE_ARR, CH_ARR, true, V>(p, strip, ra, rb);
     else
         stream_body<T, NT, CE_ARR, CH_ARR, false, V>(p, strip, ra, rb);
-}
-
-template <class T, int NT, bool CE_ARR, bool CH_ARR, bool WIDE = false>
-__global__ __launch_bounds__(PASS_THREADS) void k_zone(const PassParams<T> p)
-{
-    const int z = blockIdx.x / p.zone_tiles;
-    if constexpr (ZoneDims<NT, WIDE>::LDS_ELEMS * sizeof(T) > 65536) {      // beyond the static limit: dynamic LDS
-        extern __shared__ __attribute__((aligned(16))) unsigned char zone_dyn[];
-        zone_body<T, NT, CE_ARR, CH_ARR, PASS_THREADS, WIDE>(p, blockIdx.x - z * p.zone_tiles, p.zone_top ? z == 1 : true,
-                                                             reinterpret_cast<T *>(zone_dyn));
-    } else {
-        __shared__ T smem[ZoneDims<NT, WIDE>::LDS_ELEMS];
-        zone_body<T, NT, CE_ARR, CH_ARR, PASS_THREADS, WIDE>(p, blockIdx.x - z * p.zone_tiles, p.zone_top ? z == 1 : true, smem);
-    }
 }
 
 }  // namespace fdtd

@@ -20,8 +20,12 @@ template <bool CE_ARR> static int launch_pml_split(fdtd2d *h, fdtd::PassParams<f
     while (n_left < ns && x0_of(n_left) < L + 1) ++n_left;
     while (n_right < ns - n_left && x0_of(ns - 1 - n_right) + SW > C - 1 - L) ++n_right;
     const int inner = ns - n_left - n_right;
-    // rows whose 16-step cone can touch the top / bottom layer: [0, L + 1 + 2 NT) and the mirror
-    const int reach = L + 1 + 2 * NT;
+    // Rows the plain kernel must stay clear of: a band [ra, rb) computes level t >= 1 on the rows >= ra - NT (level 1
+    // reaches furthest up; rows above that only enter as level-0 data), and every row it COMPUTES must be outside the row
+    // layers, i.e. >= L -- so its first band may start at L + NT, and the layer kernel's top task holds L + NT rows (56
+    // for L = 40; until round 3 this was the whole 16-step cone of the output rows, L + 1 + 2 NT -> 80 rows: 131 ticks
+    // per task instead of 107).  Mirror image at the bottom.
+    const int reach = L + NT;
     const int re = std::max(16, h->shape_now.edge_rows > 0 ? h->shape_now.edge_rows : h->pml_layer_rows);
     auto up8 = [&](int x) { return (x + 7) / 8 * 8; };
     int a_hi = p.band_lo, c_lo = p.band_hi;
@@ -44,6 +48,9 @@ template <bool CE_ARR> static int launch_pml_split(fdtd2d *h, fdtd::PassParams<f
     pp.nbands_e = 0;
     pp.band_rows_e = pp.band_rows;
     pp.nbands = (std::max(0, c_lo - a_hi) + pp.band_rows - 1) / pp.band_rows;
+    pp.n_inner = inner;
+    pp.band_rows2 = pp.nbands2 = 0;
+    pp.split_row = c_lo;
     const long long plain_blocks = (long long)pp.nbands * inner;
     // side by side on two streams where the piece is large; the 16-row pieces next to a slab's cuts run their two
     // kernels one after the other on the handle's stream (a fork / join pair of events costs more than they take)

@@ -19,6 +19,8 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
     const int region = std::max(0, p.band_hi - p.band_lo);
     p.nbands = (region + p.band_rows - 1) / p.band_rows;
     p.nbands_e = (region + p.band_rows_e - 1) / p.band_rows_e;
+    p.band_rows2 = p.nbands2 = 0;
+    p.split_row = p.band_hi;
     // inner strips that hold source columns (at most two neighbours; wider sources get no special bands)
     p.src_strip = 0;
     p.n_src = 0;
@@ -40,13 +42,36 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
         }
     }
     p.zone_tiles = (h->cols + D::WZ - 1) / D::WZ;
+#ifdef FDTD2D_TUNE_LOG      // profiling build only: the launch WITHOUT its zone tiles (wrong results; what would cheaper tiles buy?)
+    if (std::getenv("FDTD2D_DEBUG_NOZONES")) p.zone_top = p.zone_bot = 0;
+#endif
     // launch order: zone tiles, 2 edge-strip slots (the second stays empty with one strip),
     // then strips 1 .. nstrips-2
+    p.n_inner = std::max(0, p.nstrips - 2 - p.n_src);
+    {   // filler bands (Shape::short_rows): the bottom rows of the inner strips in shorter bands that come last
+        const fdtd2d::Shape &sh = h->shape_now;
+        const bool xcd_now = h->xcd_map >= 0 ? h->xcd_map != 0 : sh.xcd != 0;
+        if (sh.short_rows >= 8 && sh.n_short > 0 && !xcd_now && NT >= 8 && p.n_inner > 0 &&
+            (long long)sh.short_rows * sh.n_short < region && h->use_level_split(NT, p.band_lo, p.band_hi)) {
+            p.band_rows2 = sh.short_rows;
+            p.nbands2 = sh.n_short;
+            p.split_row = p.band_hi - sh.short_rows * sh.n_short;
+            p.nbands = (p.split_row - p.band_lo + p.band_rows - 1) / p.band_rows;
+        }
+    }
     long long bulk = 2LL * p.nbands_e + (long long)p.n_src * p.nbands_s +
-                     (long long)p.nbands * std::max(0, p.nstrips - 2 - p.n_src);
-    const long long zones = (long long)(p.zone_top + p.zone_bot) * p.zone_tiles;
+                     (long long)(p.nbands + p.nbands2) * p.n_inner;
+    const int zone_tiles_all = (p.zone_top + p.zone_bot) * p.zone_tiles;
+    // workgroups of the zone tiles: in the fused launch (64 x waves-per-strip threads) and as k_zone (256 threads)
+    const int nw_now = NT >= 8 && h->use_level_split(NT, p.band_lo, p.band_hi) ? h->split_waves_for(NT, p.band_lo, p.band_hi) : 1;
+    const int zones_fused = nw_now == 8 ? fdtd::zone_wgs_for<T, NT, 512>(zone_tiles_all)
+                          : (nw_now == 4 ? fdtd::zone_wgs_for<T, NT, 256>(zone_tiles_all) : zone_tiles_all);
+    const int zones_side = NT >= 8 && h->use_level_split(NT, p.band_lo, p.band_hi)
+                               ? fdtd::zone_wgs_for<T, NT, fdtd::PASS_THREADS>(zone_tiles_all) : zone_tiles_all;
+    const long long zones = zones_fused;
+    p.zone_wgs = zones_fused;
     p.xcd_map = 0;
-    p.main_pad = p.main_per = p.main_tasks = p.n_inner = 0;
+    p.main_pad = p.main_per = p.main_tasks = 0;
     const bool xcd = h->xcd_map >= 0 ? h->xcd_map != 0 : h->shape_now.xcd != 0;
     if (xcd && NT >= 8 && h->use_level_split(NT, p.band_lo, p.band_hi) && p.nstrips - 2 - p.n_src > 0) {
         // (the zone tiles ride in front of the bulk when fused: the pad makes the first inner-strip task a multiple
@@ -54,7 +79,6 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
         const bool side = zones > 0 && (h->zone_split == 1 || NT > 16 || sd > 1);
         const long long front = (side ? 0 : zones) + 2LL * p.nbands_e + (long long)p.n_src * p.nbands_s;
         p.xcd_map = 1;
-        p.n_inner = p.nstrips - 2 - p.n_src;
         p.main_tasks = p.nbands * p.n_inner;
         p.main_per = (p.main_tasks + 7) / 8;
         p.main_pad = (int)((8 - front % 8) % 8);
@@ -92,7 +116,7 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
                     }
                 }
                 if (!wide)
-                    hipLaunchKernelGGL((fdtd::k_zone<T, NT, CE_ARR, CH_ARR>), dim3((unsigned)zones),
+                    hipLaunchKernelGGL((fdtd::k_zone<T, NT, CE_ARR, CH_ARR>), dim3((unsigned)zones_side),
                                        dim3(fdtd::PASS_THREADS), 0, h->side_stream, p);
                 HIPCHK(h, hipGetLastError());
                 HIPCHK(h, hipEventRecord(h->ev_join, h->side_stream));
@@ -297,7 +321,8 @@ template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, 
     h->shape_last = fdtd2d::Shape{p.band_rows,
                                   h->pml_split(nt) ? 4 : (h->use_level_split(nt, band_lo, band_hi) ? h->split_waves_for(nt, band_lo, band_hi) : 1),
                                   h->pml_split(nt) ? (h->shape_now.edge_rows > 0 ? h->shape_now.edge_rows : h->pml_layer_rows) : p.band_rows_e,
-                                  h->shape_now.side, h->xcd_map >= 0 ? h->xcd_map : h->shape_now.xcd};
+                                  h->shape_now.side, h->xcd_map >= 0 ? h->xcd_map : h->shape_now.xcd,
+                                  h->shape_now.short_rows, h->shape_now.n_short};
     p.zone_top = ztop;
     p.zone_bot = zbot;
     p.trash = (T *)h->trash;
@@ -310,6 +335,8 @@ template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, 
     // over the grid for a tail of 3, 5, 6, 7, 9..15 steps instead of one per power of two)
     p.strip_first = 1;
     p.xcd_map = p.main_pad = p.main_per = p.main_tasks = p.n_inner = 0;
+    p.band_rows2 = p.nbands2 = 0;
+    p.split_row = band_hi;
     p.src_strip = p.n_src = 0;
     p.band_rows_s = p.nbands_s = 1;
     p.nlev = nlev > 0 ? std::min(nlev, nt) : nt;

@@ -294,7 +294,7 @@ class Engine:
         return self
 
     def set_option(self, max_pass_steps=None, band_rows=None, zone_split=None, level_split=None,
-                   split_waves=None, autotune=None, long_shape=None, xcd_map=None, side_waves=None):
+                   split_waves=None, autotune=None, xcd_map=None, side_waves=None):
         """Speed knobs of run(): longest temporally blocked pass (0 = single-step kernels
         only) and rows per streaming band.  Results do not depend on them."""
         if max_pass_steps is not None:
@@ -313,12 +313,15 @@ class Engine:
             self._ck(self._lib.fdtd2d_set_option(self._h, _abi.OPT_SIDE_WAVES, int(side_waves)))
         if xcd_map is not None:
             self._ck(self._lib.fdtd2d_set_option(self._h, _abi.OPT_XCD_MAP, int(xcd_map)))
-        if long_shape is not None:       # (band rows, waves per strip[, edge band rows[, pass length[, waves side by
-            br, nw, *er = long_shape     # side[, xcd map]]]]); pass length 0 / absent = the full-length passes
-            er = list(er) + [0] * (4 - len(er))
-            self._ck(self._lib.fdtd2d_set_option(self._h, _abi.OPT_LONG_SHAPE,
-                                                 int(br) + 65536 * int(nw) + (int(er[0]) << 32) + (int(er[1]) << 48)
-                                                 + (int(er[2]) << 56) + (int(er[3]) << 59)))
+        return self
+
+    def set_shape(self, shape, pass_steps=0):
+        """Launch shape of the passes of `pass_steps` steps (0 = the full-length ones): (band rows, waves per level
+        group, edge band rows, waves side by side, xcd map, filler band rows, filler bands per strip) -- what
+        last_shape returns, e.g. from another process.  Results do not depend on it."""
+        v = [int(x) for x in shape]
+        arr = (C.c_int * len(v))(*v)
+        self._ck(self._lib.fdtd2d_set_shape(self._h, int(pass_steps), arr, len(v)))
         return self
 
     def sync(self):
@@ -451,10 +454,11 @@ class Engine:
 
     @property
     def last_shape(self):
-        """(band rows, waves per level group, band rows of the first / last strip, waves side by side, xcd map) of the
-        last pass."""
-        return (self.info(_abi.INFO_LAST_BAND_ROWS), self.info(_abi.INFO_LAST_WAVES), self.info(_abi.INFO_LAST_EDGE_ROWS),
-                self.info(_abi.INFO_LAST_SIDE_WAVES), self.info(_abi.INFO_LAST_XCD_MAP))
+        """(band rows, waves per level group, band rows of the first / last strip, waves side by side, xcd map, filler
+        band rows, filler bands per strip) of the last pass."""
+        out = (C.c_int * 7)()
+        self._ck(self._lib.fdtd2d_last_shape(self._h, out, 7))
+        return tuple(int(v) for v in out)
 
     @property
     def last_pass_steps(self) -> int:

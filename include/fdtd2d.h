@@ -243,12 +243,7 @@ int fdtd2d_sync(fdtd2d_t *h);
                                          times a ladder of band heights (and 4 / 8 waves per strip)
                                          with uncommitted trial launches and keeps the fastest;
                                          0: fixed rules.  Results are identical either way. */
-#define FDTD2D_OPT_LONG_SHAPE      6   /* launch shape of the passes of one length, value = band rows + 2^16 *
-                                         waves per strip (0 = automatic) + 2^32 * band rows of the first /
-                                         last strip (0 = the same) + 2^48 * pass length (0 = the full-length
-                                         passes, 16 or 8 steps; 20 = the 20-step remainder pass) + 2^56 * waves
-                                         side by side (0 = 1) + 2^59 * xcd map: re-use a shape the tuner found
-                                         in another process; band rows 0 clears it */
+/* (6: reserved -- launch shapes are handed over with fdtd2d_set_shape) */
 #define FDTD2D_OPT_XCD_MAP         7   /* task order of the level-split pass: 1 = every XCD (workgroups b, b + 8, ...
                                          under the round-robin placement the hardware is observed to use) gets a
                                          contiguous run of (band, strip) tasks with the strips of one band next to
@@ -260,6 +255,17 @@ int fdtd2d_sync(fdtd2d_t *h);
                                          LDS hand-off -- the 32 overlap columns of a strip are paid once per 504 / 1000
                                          columns instead of per 256; 1 = never; 0 (default) = the tuner decides. */
 int fdtd2d_set_option(fdtd2d_t *h, int option, long long value);
+
+/* Launch shape of the temporally blocked passes of `pass_steps` steps (0 = the full-length passes, 16 or 8): re-use
+ * a shape the tuner found elsewhere (another process, an earlier run).  shape[0..n): band rows, waves per level group
+ * (0 = automatic, 4, 8), band rows of the first / last strip (0 = the same), waves side by side per level group (1, 2,
+ * 4), xcd map (0 / 1), and for launches that fit the GPU in one round: rows and number per strip of the shorter "filler"
+ * bands that take over the slots the zone tiles free (0, 0 = none); missing trailing entries are 0 (side: 1);
+ * shape[0] = 0 clears it.  fdtd2d_last_shape returns the shape the last pass ran with, in the same order.  Results never
+ * depend on the shape. */
+#define FDTD2D_SHAPE_LEN 7
+int fdtd2d_set_shape(fdtd2d_t *h, int pass_steps, const int *shape, int n);
+int fdtd2d_last_shape(const fdtd2d_t *h, int *shape, int n);
 
 /* ---- row-slab halo exchange (transport is the caller's: RCCL via torch.distributed) -- */
 

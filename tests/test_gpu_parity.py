@@ -893,3 +893,32 @@ def test_strips_of_several_waves_side_by_side_match_oracle(fd, onp, side, shape,
         assert eng.info(16) == 2 and eng.last_shape[3] == side and eng.last_shape[4] == xcd and eng.last_pass_steps == 20
     for a, b, k in zip(got, ref, ("Ez", "Hx", "Hy")):
         assert np.array_equal(a, b), f"{k} side={side} {kind}: {np.argwhere(a != b)[:4]}"
+
+
+@pytest.mark.parametrize("shape,steps", [((60, 4, 0, 1, 0, 40, 2), 0), ((100, 8, 50, 1, 0, 24, 3), 0), ((48, 4, 24, 1, 0, 16, 5), 0),
+                                         ((64, 0, 0, 1, 0, 32, 2), 8)])
+@pytest.mark.parametrize("kind", ["uniform", "eps+mu"])
+def test_filler_bands_match_oracle(fd, onp, shape, steps, kind):
+    """Launch shapes with "filler" bands (fdtd2d_set_shape: the last bands of every inner strip shorter and last in
+    launch order, for launches that fit the GPU in one round): 16-step passes (8-step ones in the last case), 35
+    steps = two full passes + a short one, from a random state, source on the seam between tall and filler bands.
+    Value-identical to the oracle; the shape really ran."""
+    r, c = 300, 1100
+    rng = np.random.default_rng(sum(shape))
+    Ez, Hx, Hy, eps, mu = _random_state(rng, r, c, np.float32, onp, vary_mu=(kind == "eps+mu"))
+    if kind == "uniform":
+        eps = np.full((r, c), 2.3 * onp.EPS0, np.float32)
+    n = 35
+    amps = rng.standard_normal(n)
+    nt = steps or 16
+    src = (r - (5 + nt) - shape[5] * shape[6], 500)
+    ref = [a.copy() for a in (Ez, Hx, Hy)]
+    onp.leapfrog(*ref, eps, mu, DT, DX, n, src[0], src[1], amps=amps)
+    with fd.Engine(r, c, DT, DX, dtype=np.float32) as eng:
+        eng.set_materials(eps, mu).set_option(max_pass_steps=nt).set_shape(shape, steps)
+        eng.upload(Ez, Hx, Hy)
+        eng.run(n, src[0], src[1], amps)
+        got = eng.download()
+        assert eng.last_shape[5:] == shape[5:] and eng.last_shape[0] == shape[0]
+    for a, b, k in zip(got, ref, ("Ez", "Hx", "Hy")):
+        assert np.array_equal(a, b), f"{k} {shape} {kind}: {np.argwhere(a != b)[:4]}"

@@ -24,7 +24,7 @@ os.environ["FDTD2D_TRACE_FILE"] = path
 with fd.Engine(g, g, dtype=np.float32) as e:
     e.set_materials()
     if br:
-        e.set_option(long_shape=(br, nw))
+        e.set_shape((br, nw))
     N = int(os.environ.get("TRACE_N", "16"))      # pass length to look at (16, 20 or 24)
     e.prepare(N)
     e.run(N * 4)

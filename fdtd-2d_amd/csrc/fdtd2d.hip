@@ -1019,7 +1019,8 @@ static int tune_pass(fdtd2d *h, int nt, int lo, int hi, bool zt, bool zb, int sr
                         const double er = life / w_e - fill;                   // rows of an equally long edge task
                         const int ne = w_e == 1.0 ? nb : (er >= 8 ? (int)std::ceil(region / er) : region / 8);
                         const int brs = std::max(16, std::min((region + ne - 1) / ne, (region + nb - 1) / nb / 3));
-                        const int n_s = n_src * ((region + brs - 1) / brs);          // workgroups of the source strips
+                        // workgroups of the source strips: short bands on the ~3 nt rows around the source only
+                        const int n_s = n_src * (nb + 1 + (3 * nt + h->src_rows + brs - 1) / brs);
                         if ((double)std::max(0, ns - 2 - n_src) * nb + 2.0 * ne + n_s > tasks) break;
                         best = fdtd2d::Shape{(region + nb - 1) / nb, (both_nw || sd > 1) ? nw : 0,
                                              w_e == 1.0 ? 0 : std::max(8, (region + ne - 1) / ne), sd};
@@ -1041,7 +1042,7 @@ static int tune_pass(fdtd2d *h, int nt, int lo, int hi, bool zt, bool zb, int sr
                             const double life = rl + fill, er = life / w_e - fill;
                             const int ne = w_e == 1.0 ? (region + rl - 1) / rl : (er >= 8 ? (int)std::ceil(region / er) : region / 8);
                             const int brs = std::max(16, std::min((region + ne - 1) / ne, rl / 3));
-                            const int n_s = n_src * ((region + brs - 1) / brs);
+                            const int n_s = n_src * (nl + nshort + 1 + (3 * nt + h->src_rows + brs - 1) / brs);
                             if ((double)n_i * nl + 2.0 * ne + n_s > (double)slots - zones) break;
                             best = fdtd2d::Shape{rl, both_nw ? nw : 0, w_e == 1.0 ? 0 : std::max(8, (region + ne - 1) / ne), 1, 0, rs, nshort};
                         }

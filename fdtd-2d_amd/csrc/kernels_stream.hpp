@@ -57,7 +57,10 @@ template <class T> struct PassParams {
                                // to another kernel and sets nbands_e = 0)
     int src_strip, n_src;      // inner strips [src_strip, src_strip + n_src) hold the source columns: their
     int band_rows_s, nbands_s; // workgroups near the source rows run the slower GENERAL body too and would end
-                               // the launch alone, so these strips get short bands of their own (n_src = 0: none)
+                               // the launch alone, so the rows [src_lo, src_hi) around the source get short bands of
+                               // their own in these strips (n_src = 0: none); the rows above and below keep band_rows:
+    int src_lo, src_hi;        // nsrc_top bands of band_rows, then nsrc_mid of band_rows_s, then the rest (nbands_s in all)
+    int nsrc_top, nsrc_mid;
     int xcd_map;               // 1: the inner strips' tasks are dealt out XCD by XCD (FDTD2D_OPT_XCD_MAP)
     int main_pad, main_per, main_tasks, n_inner;   // (with xcd_map) empty blocks in front of them, tasks per XCD, tasks, strips
     int band_rows2, nbands2, split_row;   // "filler" bands: the rows [split_row, band_hi) of the inner strips in nbands2
@@ -187,10 +190,19 @@ __device__ __forceinline__ bool strip_of_block(const PassParams<T> &p, int b, in
         *ra = p.band_lo + band * p.band_rows_e;
         *rb = min(*ra + p.band_rows_e, p.band_hi);
     } else if ((b -= 2 * p.nbands_e) < p.n_src * p.nbands_s) {
-        const int sidx = b / p.nbands_s, band = b - sidx * p.nbands_s;
+        const int sidx = b / p.nbands_s;
+        int band = b - sidx * p.nbands_s;
         *strip = p.src_strip + sidx;
-        *ra = p.band_lo + band * p.band_rows_s;
-        *rb = min(*ra + p.band_rows_s, p.band_hi);
+        if (band < p.nsrc_top) {
+            *ra = p.band_lo + band * p.band_rows;
+            *rb = min(*ra + p.band_rows, p.src_lo);
+        } else if ((band -= p.nsrc_top) < p.nsrc_mid) {
+            *ra = p.src_lo + band * p.band_rows_s;
+            *rb = min(*ra + p.band_rows_s, p.src_hi);
+        } else {
+            *ra = p.src_hi + (band - p.nsrc_mid) * p.band_rows;
+            *rb = min(*ra + p.band_rows, p.band_hi);
+        }
     } else {
         b -= p.n_src * p.nbands_s;
         int sidx, band;

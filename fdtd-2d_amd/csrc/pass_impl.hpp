@@ -25,7 +25,15 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
     p.src_strip = 0;
     p.n_src = 0;
     p.band_rows_s = std::max(16, std::min(p.band_rows_e, p.band_rows / 3));
-    p.nbands_s = (region + p.band_rows_s - 1) / p.band_rows_s;
+    {   // short bands only on the rows whose workgroups can see the source: a band [ra, rb) runs the general body iff
+        // ra - 2 NT < src_row1 and rb + NT > src_row, so the bands above src_row - NT and below src_row1 + 2 NT are plain
+        auto clampi = [](int v, int a, int b) { return std::min(std::max(v, a), b); };
+        p.src_lo = clampi(p.src_row - NT, p.band_lo, p.band_hi);
+        p.src_hi = clampi(p.src_row1 + 2 * NT, p.src_lo, p.band_hi);
+        p.nsrc_top = (p.src_lo - p.band_lo + p.band_rows - 1) / p.band_rows;
+        p.nsrc_mid = (p.src_hi - p.src_lo + p.band_rows_s - 1) / p.band_rows_s;
+        p.nbands_s = p.nsrc_top + p.nsrc_mid + (p.band_hi - p.src_hi + p.band_rows - 1) / p.band_rows;
+    }
     if (p.src_col1 > p.src_col && p.band_rows_s < p.band_rows && p.nstrips > 2) {
         const int SWc = sd > 1 ? fdtd::strip_width(NT / 4, V, sd) : 64 * V, OWc = SWc - 2 * fdtd::stream_hc(NT);
         int s0 = -1, s1 = -1;
@@ -339,6 +347,8 @@ template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, 
     p.split_row = band_hi;
     p.src_strip = p.n_src = 0;
     p.band_rows_s = p.nbands_s = 1;
+    p.src_lo = p.src_hi = band_hi;
+    p.nsrc_top = p.nsrc_mid = 0;
     p.nlev = nlev > 0 ? std::min(nlev, nt) : nt;
     if (p.nlev != nt && !h->use_level_split(nt, band_lo, band_hi) && !h->pml_split(nt))
         return fail(h, FDTD2D_E_ARG, "short passes run on the level-split kernels only");

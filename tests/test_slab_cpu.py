@@ -113,9 +113,10 @@ def _check(got, st, dtype, nsteps, src):
         assert a.shape == b.shape and np.array_equal(a, b), k
 
 
-@pytest.mark.parametrize("rows,overlapped", [(99, True), (98, False)])
+@pytest.mark.parametrize("rows,overlapped", [(111, True), (110, False)])
 def test_three_ranks_agree_on_the_exchange_mode(tmp_path, rows, overlapped):
-    """99 rows = three 33-row slabs: every rank may overlap (2*16+1 rows).  98 rows = 33/33/32:
+    """111 rows = three 37-row slabs: every rank may overlap (2*16+5 rows: two 16-row edge pieces and, on the first /
+    last rank, an interior piece that holds the whole 21-row zone).  110 rows = 37/37/36:
     the short slab cannot, so NO rank does -- a per-rank decision would leave ranks 0 and 1 in the
     overlapped cycle (send after the pass) and rank 2 in the plain one (send before it): deadlock."""
     c, n = 18, 40
@@ -136,14 +137,14 @@ def test_ranks_whose_engines_disagree_use_the_shortest_cycle(tmp_path):
     _check(run_job(3, job, str(tmp_path)), st, "float32", n, (50, 4))
 
 
-@pytest.mark.parametrize("world,rows", [(4, 136), (8, 272), (8, 180)])
+@pytest.mark.parametrize("world,rows", [(4, 152), (8, 304), (8, 180)])
 def test_four_and_eight_slabs(tmp_path, world, rows):
     """BASELINE configs 4 and 5 decompose into 4 and 8 slabs: interior ranks have two neighbours,
-    the source sits on a cut, 34-row slabs overlap (16-step cycles), 22-row slabs do not."""
+    the source sits on a cut, 38-row slabs overlap (16-step cycles), 22-row slabs do not."""
     c, n = 14, 35
     st, path = _state(str(tmp_path), rows, c, world * rows, n, vary_mu=True)
     src = (rows // 2, 6)
-    tall = rows // world >= 33
+    tall = rows // world >= 37
     job = dict(engine="fake", shape=(rows, c), dtype="float32", dt=DT, dx=DX, state=path, src=src,
                chunks=[16, 19], materials="array", overlap=True, cycle=16, expect_overlap=tall)
     _check(run_job(world, job, str(tmp_path)), st, "float32", n, src)

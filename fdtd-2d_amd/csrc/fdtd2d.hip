@@ -1152,7 +1152,7 @@ static int tune_pass(fdtd2d *h, int nt, int lo, int hi, bool zt, bool zb, int sr
             }
             per_side[sd]++;
         }
-        if (split && h->xcd_map < 0 && !h->pml_split(nt))
+        if ((split || h->pml_split(nt)) && h->xcd_map < 0)
             for (size_t k = 0, n = fin.size(); k < n; ++k) {
                 fdtd2d::Shape t = fin[k];
                 t.xcd = 1;

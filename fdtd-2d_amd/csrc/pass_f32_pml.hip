@@ -51,7 +51,15 @@ template <bool CE_ARR> static int launch_pml_split(fdtd2d *h, fdtd::PassParams<f
     pp.n_inner = inner;
     pp.band_rows2 = pp.nbands2 = 0;
     pp.split_row = c_lo;
-    const long long plain_blocks = (long long)pp.nbands * inner;
+    long long plain_blocks = (long long)pp.nbands * inner;
+    // the plain kernel's tasks dealt out XCD by XCD (FDTD2D_OPT_XCD_MAP / the tuner's choice), as in launch_pass_impl
+    if ((h->xcd_map >= 0 ? h->xcd_map != 0 : h->shape_now.xcd != 0) && plain_blocks > 0) {
+        pp.xcd_map = 1;
+        pp.main_tasks = (int)plain_blocks;
+        pp.main_per = (pp.main_tasks + 7) / 8;
+        pp.main_pad = 0;
+        plain_blocks = 8LL * pp.main_per;
+    }
     // side by side on two streams where the piece is large; the 16-row pieces next to a slab's cuts run their two
     // kernels one after the other on the handle's stream (a fork / join pair of events costs more than they take)
     const bool both = layer_blocks > 0 && plain_blocks > 0 && region >= 256;

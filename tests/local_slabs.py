@@ -18,7 +18,7 @@ def run_local_slabs(fd, world, shape, dtype, boundary, st, nsteps, src, *, cycle
                     materials="array", extent=None, pml=None):
     """Returns (Ez, Hx, Hy) of the whole grid assembled from the ranks' owned rows, plus the cycle used.
     st: dict with full-grid Ez, Hx, Hy, eps, mu, amps (float64; cast here)."""
-    import torch
+    import hipmem
     from fdtd2d_amd.slab import plan_slabs, HALO
     rows, cols = shape
     dt_ = np.dtype(dtype)
@@ -46,33 +46,31 @@ def run_local_slabs(fd, world, shape, dtype, boundary, st, nsteps, src, *, cycle
     for e in engines:
         if e.cycle_steps != cycle:
             e.set_option(max_pass_steps=cycle)
-    td = torch.float32 if dt_ == np.float32 else torch.float64
     for k, eng in enumerate(engines):
-        n = eng.halo_bytes // dt_.itemsize
         b = {}
         for side, has in ((0, k > 0), (1, k < world - 1)):
             if has:
-                b[side] = (torch.zeros(n, dtype=td, device="cuda:0"), torch.zeros(n, dtype=td, device="cuda:0"))
+                b[side] = (hipmem.DevBuf(eng.halo_bytes), hipmem.DevBuf(eng.halo_bytes))      # (send, recv)
         bufs.append(b)
-    torch.cuda.synchronize()
+    hipmem.sync()
     barrier = threading.Barrier(world)
     errors = []
 
     def transport(k):
         def fn(_st, _rt, _sb, _rb, _nbytes, _stream):
-            torch.cuda.synchronize()                 # this rank's packs (and everyone else's) are done
+            hipmem.sync()                            # this rank's packs (and everyone else's) are done
             barrier.wait(timeout=120)
             if 0 in bufs[k]:
-                bufs[k][0][1].copy_(bufs[k - 1][1][0])       # my top halo <- upper neighbour's bottom rows
+                bufs[k][0][1].copy_from(bufs[k - 1][1][0])   # my top halo <- upper neighbour's bottom rows
             if 1 in bufs[k]:
-                bufs[k][1][1].copy_(bufs[k + 1][0][0])       # my bottom halo <- lower neighbour's top rows
-            torch.cuda.synchronize()
+                bufs[k][1][1].copy_from(bufs[k + 1][0][0])   # my bottom halo <- lower neighbour's top rows
+            hipmem.sync()
             barrier.wait(timeout=120)                # nobody repacks before every copy has been made
             return 0
         return fn
 
     for k, eng in enumerate(engines):
-        eng.slab_attach({s: (b[0].data_ptr(), b[1].data_ptr()) for s, b in bufs[k].items()}, transport(k))
+        eng.slab_attach({s: (b[0].ptr, b[1].ptr) for s, b in bufs[k].items()}, transport(k))
     min_slab = min(b - a for a, b in plan)
     can_overlap = bool(overlap) and min_slab >= 2 * halo + 5 and rows >= 2 * (2 * cycle + 6)
 

@@ -278,11 +278,10 @@ def test_c_loop_refuses_overlap_on_slabs_that_cut_the_zone():
     r, c = 105, 300
     with fd.Engine(r, c, DT, DX, dtype=np.float32, slab=(0, 35, 16)) as eng:
         eng.set_materials().set_option(max_pass_steps=16)
-        import torch
-        n = eng.halo_bytes // 4
-        send, recv = torch.zeros(n, device="cuda:0"), torch.zeros(n, device="cuda:0")
+        import hipmem
+        send, recv = hipmem.DevBuf(eng.halo_bytes), hipmem.DevBuf(eng.halo_bytes)
         called = []
-        eng.slab_attach({1: (send.data_ptr(), recv.data_ptr())}, lambda *a: called.append(a) or 0)
+        eng.slab_attach({1: (send.ptr, recv.ptr)}, lambda *a: called.append(a) or 0)
         with pytest.raises(_abi.Fdtd2dError) as e:
             eng.run_slab(16, 16, True)
         assert e.value.code == _abi.E_ARG and not called

@@ -225,7 +225,7 @@ def test_full_size_pml_slab_of_config5(rank):
     16 halo rows, array eps; halos filled from a random message (what a neighbour would send), 16 steps: the
     16-step pair == 8-step passes + ... == single-step kernels on every owned cell.  Rank 0 / 7 own the top /
     bottom layer, rank 3 only the column layers."""
-    import torch
+    import hipmem
     import fdtd2d_amd as fd
     R = C = 32768
     r0, nr, halo, L = 4096 * rank, 4096, 16, 40
@@ -242,7 +242,7 @@ def test_full_size_pml_slab_of_config5(rank):
     m = rng.standard_normal((4, halo, C), dtype=np.float32) * np.float32(1e-3)
     m[1, :, L:C - L] = 0
     m[2, :, C - 1] = 0
-    msg = torch.from_numpy(m.reshape(-1)).to("cuda:0")
+    msg = hipmem.DevBuf(m.nbytes).upload(m)
 
     def make():
         eng = fd.Engine(R, C, DT, DX, dtype=np.float32, boundary="pml", slab=(r0, nr, halo))
@@ -252,7 +252,7 @@ def test_full_size_pml_slab_of_config5(rank):
         eng.upload(*init)
         for side in (0, 1):
             if (side == 0 and rank > 0) or (side == 1 and rank < 7):
-                eng.halo_unpack(side, msg.data_ptr())
+                eng.halo_unpack(side, msg.ptr)
         eng.sync()
 
     outs = _pml_three_ways(make, fill, n=16)

@@ -104,10 +104,36 @@ class Fdtd2dError(RuntimeError):
         self.code = code
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  ROCm wheels of torch bundle their own libamdhip64.so / libhsa-runtime64.so (same
+    SONAMEs as /opt/rocm's, other files).  Imported first, torch's copies satisfy libfdtd2d.so's dependency and the process
+    holds one runtime; imported AFTER libfdtd2d.so, torch maps its copies beside the system's, and the runtime that
+    initialises second can find the GPU taken (round 3: "No HIP GPUs are available" in a test process after 440 tests).
+    SlabRunner and bench.py need torch in the same process (streams, RCCL), so where torch is installed its copy is
+    mapped first, whatever the import order.  FDTD2D_SYSTEM_HIP=1 keeps the system's runtime."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("FDTD2D_SYSTEM_HIP"):
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    for d in (spec.submodule_search_locations or []) if spec else []:
+        for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+            path = os.path.join(d, "lib", name)
+            if os.path.exists(path):
+                try:
+                    C.CDLL(path, mode=C.RTLD_GLOBAL)
+                except OSError:
+                    return
+
+
 def load():
     """Load libfdtd2d.so and declare every prototype.  Raises if it is not built."""
     global _lib
     if _lib is None:
+        _share_torch_hip_runtime()
         if not os.path.exists(LIB_PATH):
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "

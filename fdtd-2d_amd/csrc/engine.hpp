@@ -120,7 +120,10 @@ struct fdtd2d {
     {
         (void)band_lo, (void)band_hi;
         if ((nt != 8 && nt != 16 && nt != 20) || boundary != FDTD2D_BOUNDARY_MUR5) return false;
-        if (nt >= 16) return dtype == FDTD2D_F32;      // 16- and 20-step passes exist in this form only
+        // 16- and 20-step passes exist in this form only; 20 steps in float32 only; float64's 16-step kernel has no
+        // probe tile (its LDS tile would not fit) -- such handles stay with 8-step passes
+        if (nt > 16) return dtype == FDTD2D_F32;
+        if (nt == 16) return dtype == FDTD2D_F32 || !probe_cap;
         // array materials: only the build with fused zone tiles exists
         if ((!ce_uniform || !ch_uniform) && zone_split == 1) return false;
         return level_split != 0;
@@ -185,8 +188,11 @@ struct fdtd2d {
         // (PML: only when the 16-step pair can really run -- factor arrays set and equal to 1 outside the
         // layer, uniform mu, no probe: callers use this figure as their exchange cycle and then ask
         // fdtd2d_pass_rows for passes of exactly that length)
-        if (max_nt >= 16 && (big || max_nt_forced) && dtype == FDTD2D_F32 && have_mat &&
-            (boundary == FDTD2D_BOUNDARY_MUR5 || (pml_split(16) && !probe_cap)))
+        // (float64, round 3: the same level-split kernel with 2 columns per lane; its zone tiles need 79 KB of LDS and
+        // run as k_zone beside the bulk; no probe tile)
+        if (max_nt >= 16 && (big || max_nt_forced) && have_mat &&
+            ((boundary == FDTD2D_BOUNDARY_MUR5 && (dtype == FDTD2D_F32 || !probe_cap)) ||
+             (dtype == FDTD2D_F32 && pml_split(16) && !probe_cap)))
             return 16;
         return std::min(max_nt, 8);
     }

@@ -84,7 +84,7 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
     if (xcd && NT >= 8 && h->use_level_split(NT, p.band_lo, p.band_hi) && p.nstrips - 2 - p.n_src > 0) {
         // (the zone tiles ride in front of the bulk when fused: the pad makes the first inner-strip task a multiple
         // of 8 in the index the hardware sees)
-        const bool side = zones > 0 && (h->zone_split == 1 || NT > 16 || sd > 1);
+        const bool side = zones > 0 && (h->zone_split == 1 || NT > 16 || sd > 1 || (sizeof(T) == 8 && NT == 16));
         const long long front = (side ? 0 : zones) + 2LL * p.nbands_e + (long long)p.n_src * p.nbands_s;
         p.xcd_map = 1;
         p.main_tasks = p.nbands * p.n_inner;
@@ -101,7 +101,9 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
             // k_zone on the side stream (zone_split = 1)
             // (20-step passes: 4 waves x 5 levels at 4 workgroups per CU; a fused 46-row zone tile would
             // take 48 KB of LDS from every workgroup and leave 3, so their zones always run as k_zone)
-            const bool side = zones > 0 && (h->zone_split == 1 || NT > 16 || sd > 1);
+            // (float64 16-step passes: the 38-row LDS tile is 79 KB -- k_zone with dynamic LDS beside the bulk, never fused)
+            constexpr bool big_tile = sizeof(T) == 8 && NT == 16;
+            const bool side = zones > 0 && (h->zone_split == 1 || NT > 16 || sd > 1 || big_tile);
             p.fused_zones = zones > 0 && !side;
             if (side) {
                 HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
@@ -123,9 +125,16 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
                                            dim3(fdtd::PASS_THREADS), zone_dyn, h->side_stream, p);
                     }
                 }
-                if (!wide)
+                if (!wide) {
+                    size_t zdyn = 0;
+                    if constexpr (big_tile) {
+                        zdyn = (size_t)D::LDS_ELEMS * sizeof(T);
+                        HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(&fdtd::k_zone<T, NT, CE_ARR, CH_ARR>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)zdyn));
+                    }
                     hipLaunchKernelGGL((fdtd::k_zone<T, NT, CE_ARR, CH_ARR>), dim3((unsigned)zones_side),
-                                       dim3(fdtd::PASS_THREADS), 0, h->side_stream, p);
+                                       dim3(fdtd::PASS_THREADS), zdyn, h->side_stream, p);
+                }
                 HIPCHK(h, hipGetLastError());
                 HIPCHK(h, hipEventRecord(h->ev_join, h->side_stream));
             }
@@ -166,8 +175,12 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
                 // (a piece without zone tiles can run on either build; 8-step passes over array
                 // materials only have the fused one)
                 if (p.fused_zones || (!side && NT == 8 && (CE_ARR || CH_ARR))) {
+                    if constexpr (big_tile) {
+                        return fail(h, FDTD2D_E_STATE, "float64 16-step passes take their zone tiles from k_zone");
+                    } else {
                     if (w8) hipLaunchKernelGGL((fdtd::k_bulk_split<T, NT, 8, true, CE_ARR, CH_ARR, V>), grid, wg, 0, h->stream, p);
                     else hipLaunchKernelGGL((fdtd::k_bulk_split<T, NT, 4, true, CE_ARR, CH_ARR, V>), grid, wg, 0, h->stream, p);
+                    }
                 } else if constexpr (NT == 16 || (!CE_ARR && !CH_ARR)) {
                     if (w8) hipLaunchKernelGGL((fdtd::k_bulk_split<T, NT, 8, false, CE_ARR, CH_ARR, V>), grid, wg, 0, h->stream, p);
                     else hipLaunchKernelGGL((fdtd::k_bulk_split<T, NT, 4, false, CE_ARR, CH_ARR, V>), grid, wg, 0, h->stream, p);
@@ -252,6 +265,7 @@ template <class T> int launch_probe(fdtd2d *h, int nt, const fdtd::PassParams<T>
 #ifdef FDTD_PASS_LONG_EXTERN   // the 16- and 20-step float32 kernels are built in translation units of their own
 extern template int launch_pass_nt<float, 16>(fdtd2d *, fdtd::PassParams<float> &);
 extern template int launch_pass_nt<float, 20>(fdtd2d *, fdtd::PassParams<float> &);
+extern template int launch_pass_nt<double, 16>(fdtd2d *, fdtd::PassParams<double> &);
 #endif
 
 // One pass of nt in {1,2,4,8,16} steps; amps = nt amplitudes or nullptr.
@@ -402,9 +416,7 @@ template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, 
     case 20:
         if constexpr (sizeof(T) == 4) { rc = launch_pass_nt<T, 20>(h, p); break; }
         return fail(h, FDTD2D_E_ARG, "20-step passes are built for float32 only");
-    case 16:
-        if constexpr (sizeof(T) == 4) { rc = launch_pass_nt<T, 16>(h, p); break; }
-        return fail(h, FDTD2D_E_ARG, "16-step passes are built for float32 only");
+    case 16: rc = launch_pass_nt<T, 16>(h, p); break;
     case 8: rc = launch_pass_nt<T, 8>(h, p); break;
     case 4: rc = launch_pass_nt<T, 4>(h, p); break;
     case 2: rc = launch_pass_nt<T, 2>(h, p); break;

@@ -14,8 +14,8 @@ def hip():
         # the HIP runtime the library under test is linked against: the copy already mapped into this process
         from fdtd2d_amd import _abi
         _abi.load()
-        mapped = [l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l]
-        for name in mapped[:1] + ["libamdhip64.so", "libamdhip64.so.7", "/opt/rocm/lib/libamdhip64.so"]:
+        # (by SONAME: dlopen returns the handle of the copy that is already loaded under that name)
+        for name in ["libamdhip64.so.7", "libamdhip64.so", "/opt/rocm/lib/libamdhip64.so"]:
             try:
                 _hip = C.CDLL(name)
                 break
@@ -60,7 +60,7 @@ class DevBuf:
         _ck(hip().hipMemcpy(self.ptr, other.ptr, self.nbytes, 3), "hipMemcpy D2D")
 
     def free(self):
-        if self.ptr:
+        if getattr(self, "ptr", None):
             hip().hipFree(self.ptr)
             self.ptr = None
 

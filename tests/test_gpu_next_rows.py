@@ -118,8 +118,7 @@ def test_probe_time_series_matches_oracle(tag, dtype, probe, max_steps):
     the oracle's per-step values; 45 steps with a patch source, array eps."""
     import fdtd2d_amd as fd
     from oracle import fdtd_numpy as onp
-    if max_steps == 16 and dtype != np.float32:
-        pytest.skip("16-step passes are float32")
+    # (float64 with a probe set: the 16-step kernel has no probe tile in float64 -- the engine runs 8-step passes)
     r, c, n = 130, 470, 45
     rng = np.random.default_rng(probe[0] * 7 + probe[1])
     Ez = rng.standard_normal((r, c)).astype(dtype)

@@ -600,8 +600,6 @@ def test_line_and_patch_sources_match_oracle(fd, onp, tag, dtype, src, extent, m
     """N3: the same amplitude on every cell of a rectangle (row / column lines, patches) --
     through the half-step kernels (max_steps 0), 8-step and 16-step passes, array eps."""
     r, c, n = 130, 470, 21
-    if max_steps == 16 and dtype != np.float32:
-        pytest.skip("16-step passes are float32")
     rng = np.random.default_rng(src[0] * 1000 + src[1])
     Ez, Hx, Hy, eps, mu = _random_state(rng, r, c, dtype, onp)
     amps = rng.standard_normal(n)
@@ -922,3 +920,55 @@ def test_filler_bands_match_oracle(fd, onp, shape, steps, kind):
         assert eng.last_shape[5:] == shape[5:] and eng.last_shape[0] == shape[0]
     for a, b, k in zip(got, ref, ("Ez", "Hx", "Hy")):
         assert np.array_equal(a, b), f"{k} {shape} {kind}: {np.argwhere(a != b)[:4]}"
+
+
+@pytest.mark.parametrize("kind", ["uniform", "eps", "eps+mu"])
+@pytest.mark.parametrize("split_waves", [4, 8])
+@pytest.mark.parametrize("shape,src", [((76, 64), (0, 0)), ((100, 225), (21, 223)), ((130, 470), (60, 100)), ((200, 1000), (20, 30)),
+                                       ((150, 131), (149, 130))])
+def test_float64_16_step_passes_match_oracle(fd, onp, shape, src, split_waves, kind):
+    """Round 3: the reference's own arithmetic type on the 16-step level-split kernel (2 columns per lane, 128-column
+    strips, 4 x 4 or 8 x 2 levels; the 38-row zone tiles as k_zone with 79 KB of dynamic LDS beside the bulk).  35 steps =
+    16 + 16 + a short pass of 3, from a random state; value-identical to the float64 oracle."""
+    r, c = shape
+    rng = np.random.default_rng(r * c + 64)
+    Ez, Hx, Hy, eps, mu = _random_state(rng, r, c, np.float64, onp, vary_mu=(kind == "eps+mu"))
+    if kind == "uniform":
+        eps = np.full((r, c), 1.9 * onp.EPS0)
+    n = 35
+    amps = rng.standard_normal(n)
+    ref = [a.copy() for a in (Ez, Hx, Hy)]
+    onp.leapfrog(*ref, eps, mu, DT, DX, n, src[0], src[1], amps=amps)
+    with fd.Engine(r, c, DT, DX, dtype=np.float64) as eng:
+        eng.set_materials(eps, mu).set_option(max_pass_steps=16, split_waves=split_waves, band_rows=48)
+        assert eng.cycle_steps == 16
+        eng.upload(Ez, Hx, Hy)
+        eng.run(n, src[0], src[1], amps)
+        got = eng.download()
+        assert eng.info(16) == 3 and eng.last_pass_steps == 16
+    for a, b, k in zip(got, ref, ("Ez", "Hx", "Hy")):
+        assert np.array_equal(a, b), f"{k} {shape} src={src} f64: {np.argwhere(a != b)[:4]}"
+
+
+def test_float64_16_step_passes_4096_vs_c_oracle(fd, onp, corc):
+    """float64 at a size where 16-step passes are the default (>= 12 Mi cells): 4096 x 3100, array eps, 40 steps = 16 + 12 +
+    12 with the tuner's own launch shapes; every cell equals the C oracle (float64) and the 8-step passes."""
+    r, c, n = 4096, 3100, 40
+    rng = np.random.default_rng(4096)
+    Ez, Hx, Hy, eps, mu = _random_state(rng, r, c, np.float64, onp)
+    amps = rng.standard_normal(n)
+    ref = [a.copy() for a in (Ez, Hx, Hy)]
+    corc.run(*ref, eps, mu, DT, DX, n, 2000, 1500, amps=amps)
+    outs = []
+    for max_nt in (None, 8):
+        with fd.Engine(r, c, DT, DX, dtype=np.float64) as eng:
+            eng.set_materials(eps, mu)
+            if max_nt:
+                eng.set_option(max_pass_steps=max_nt)
+            assert eng.cycle_steps == (max_nt or 16)
+            eng.upload(Ez, Hx, Hy)
+            eng.run(n, 2000, 1500, amps)
+            outs.append(eng.download())
+    for a, b, c_, k in zip(outs[0], outs[1], ref, ("Ez", "Hx", "Hy")):
+        assert np.array_equal(a, c_), f"{k}: 16-step passes vs C oracle {np.argwhere(a != c_)[:4]}"
+        assert np.array_equal(a, b), f"{k}: 16-step vs 8-step passes"

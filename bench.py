@@ -14,8 +14,9 @@ Workloads (all synthetic: zero fields, ricker source at the grid centre):
   N = 1  headline: 16384 x 16384 fp32, uniform eps/mu, Mur-5 frame -- the grid BASELINE.json's
          north_star quotes its 1-GPU target on.  The same JSON line carries, under "secondary",
          BASELINE configs[1] (4096^2 uniform), configs[2] (8192^2 ring-resonator eps map), the
-         headline grid with eps AND mu as arrays (32 B per cell-step, SURVEY.md M2's byte count) and the
-         reference's own arithmetic type, float64, at 4096^2 and 16384^2.
+         headline grid with eps AND mu as arrays (32 B per cell-step, SURVEY.md M2's byte count), one rank's
+         4096 x 32768 slab of configs[4] with the PML, and the reference's own arithmetic type, float64, at
+         4096^2 and 16384^2.
   N > 1  row slabs of 4096 rows per GPU, columns 4096*N: configs[3] (16384^2 on 4, Mur-5) and
          configs[4] (32768^2 on 8, PML) and their 2-GPU sibling; one process per GPU, halo exchange
          over RCCL.  After the timed run every rank CHECKS the rows next to its cuts against a
@@ -653,6 +654,7 @@ def main():
             recs += [(4096, 4096, 400, 40, "uniform", "mur", "f32", " (BASELINE configs[1])"),
                      (8192, 8192, 160, 32, "ring", "mur", "f32", " (BASELINE configs[2] geometry)"),
                      (16384, 16384, 160, 32, "array", "mur", "f32", " (eps and mu as arrays: 32 B per cell-step)"),
+                     (4096, 32768, 160, 32, "uniform", "pml", "f32", " (one rank's slab of BASELINE configs[4], whole-grid PML)"),
                      (4096, 4096, 160, 32, "uniform", "mur", "f64", " (the reference's own arithmetic type)"),
                      (16384, 16384, 48, 16, "uniform", "mur", "f64", " (the reference's own arithmetic type)")]
         # HBM traffic first: the rocprofv3 child processes must start before THIS process has

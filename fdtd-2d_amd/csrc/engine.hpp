@@ -148,8 +148,10 @@ struct fdtd2d {
     {
         if (sd == 1) return true;
         // (4 waves side by side = 1024 threads, at most 128 VGPRs each: only without coefficient rows in the slots)
-        return (sd == 2 || (sd == 4 && ce_uniform && ch_uniform)) && dtype == FDTD2D_F32 &&
-               boundary == FDTD2D_BOUNDARY_MUR5 && (nt == 16 || nt == 20) && cols >= 8 * 256 * sd;
+        // (float64: 2 columns per lane, strips of 128 / 248 / 488 columns: the overlap costs 25 / 13 / 7 % there)
+        const int w = dtype == FDTD2D_F32 ? 256 : 128;
+        return (sd == 2 || (sd == 4 && ce_uniform && ch_uniform)) && boundary == FDTD2D_BOUNDARY_MUR5 &&
+               (nt == 16 || (nt == 20 && dtype == FDTD2D_F32)) && cols >= 8 * w * sd;
     }
     std::map<std::array<int, 3>, Shape> tuned;
     int autotune = 1;            // FDTD2D_OPT_AUTOTUNE

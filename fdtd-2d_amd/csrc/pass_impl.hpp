@@ -149,7 +149,7 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
                 if (sd > 1) {
                     // SD waves side by side per level group (4 waves x NT / 4 levels each): 64 * 4 * SD threads, the
                     // joint hand-off rows in dynamic LDS
-                    if constexpr (sizeof(T) == 4 && (NT == 16 || NT == 20)) {
+                    if constexpr (NT == 16 || (NT == 20 && sizeof(T) == 4)) {
                         constexpr int NFc = 3 + (CE_ARR ? 1 : 0) + (CH_ARR ? 1 : 0);
                         auto go = [&](auto sdc) -> int {
                             constexpr int SDc = decltype(sdc)::value;
@@ -165,7 +165,7 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
                         else return fail(h, FDTD2D_E_ARG, "4 waves side by side: uniform materials only");
                         if (rc2) return rc2;
                     } else {
-                        return fail(h, FDTD2D_E_ARG, "strips of several waves side by side: float32 16- and 20-step passes only");
+                        return fail(h, FDTD2D_E_ARG, "strips of several waves side by side: 16-step passes and float32 20-step passes only");
                     }
                 } else if constexpr (NT > 16) {
                     // 20 steps: 4 waves x 5 levels, zone tiles on the side stream

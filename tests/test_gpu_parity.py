@@ -972,3 +972,30 @@ def test_float64_16_step_passes_4096_vs_c_oracle(fd, onp, corc):
     for a, b, c_, k in zip(outs[0], outs[1], ref, ("Ez", "Hx", "Hy")):
         assert np.array_equal(a, c_), f"{k}: 16-step passes vs C oracle {np.argwhere(a != c_)[:4]}"
         assert np.array_equal(a, b), f"{k}: 16-step vs 8-step passes"
+
+
+@pytest.mark.parametrize("side,shape", [(2, (150, 2100)), (4, (140, 4200)), (2, (131, 2048))])
+@pytest.mark.parametrize("kind", ["uniform", "eps+mu"])
+def test_float64_strips_of_several_waves_match_oracle(fd, onp, side, shape, kind):
+    """float64 16-step passes with 2 / 4 waves side by side per level group (strips of 248 / 488 columns, 2 columns
+    per lane, window overlap 2 lanes per side); 35 steps from a random state, source on a window seam."""
+    r, c = shape
+    if side == 4 and kind != "uniform":
+        pytest.skip("4 waves side by side exist for uniform materials only")
+    rng = np.random.default_rng(r + c + side)
+    Ez, Hx, Hy, eps, mu = _random_state(rng, r, c, np.float64, onp, vary_mu=(kind == "eps+mu"))
+    if kind == "uniform":
+        eps = np.full((r, c), 2.3 * onp.EPS0)
+    n = 35
+    amps = rng.standard_normal(n)
+    src = (60, 123)
+    ref = [a.copy() for a in (Ez, Hx, Hy)]
+    onp.leapfrog(*ref, eps, mu, DT, DX, n, src[0], src[1], amps=amps)
+    with fd.Engine(r, c, DT, DX, dtype=np.float64) as eng:
+        eng.set_materials(eps, mu).set_option(max_pass_steps=16, band_rows=40, side_waves=side)
+        eng.upload(Ez, Hx, Hy)
+        eng.run(n, src[0], src[1], amps)
+        got = eng.download()
+        assert eng.info(16) == 3 and eng.last_shape[3] == side
+    for a, b, k in zip(got, ref, ("Ez", "Hx", "Hy")):
+        assert np.array_equal(a, b), f"{k} side={side} {kind} f64: {np.argwhere(a != b)[:4]}"

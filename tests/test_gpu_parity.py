@@ -999,3 +999,39 @@ def test_float64_strips_of_several_waves_match_oracle(fd, onp, side, shape, kind
         assert eng.info(16) == 3 and eng.last_shape[3] == side
     for a, b, k in zip(got, ref, ("Ez", "Hx", "Hy")):
         assert np.array_equal(a, b), f"{k} side={side} {kind} f64: {np.argwhere(a != b)[:4]}"
+
+
+def test_full_size_float64_16384_columns(fd, onp, corc):
+    """float64 at a size where the tuner chooses among 1 / 2 / 4 waves side by side, XCD order and band heights by itself
+    (8192 x 16384, uniform): 40 steps (16 + 12 + 12) from a random state -- the 16-step passes equal the 8-step passes and
+    the single-step kernels on every cell; from zero fields, the window around the source equals the C oracle."""
+    r, c = 8192, 16384
+    rng = np.random.default_rng(64)
+    init = [rng.standard_normal((r, c)), rng.standard_normal((r, c - 1)) * 1e-3, rng.standard_normal((r - 1, c)) * 1e-3]
+    amps = rng.standard_normal(40)
+    outs, shapes = [], []
+    for max_nt in (None, 8, 0):
+        with fd.Engine(r, c, DT, DX, dtype=np.float64) as eng:
+            eng.set_materials()
+            if max_nt is not None:
+                eng.set_option(max_pass_steps=max_nt)
+            eng.upload(*init)
+            eng.run(40, r // 2 + 1, 5000, amps)
+            shapes.append((eng.cycle_steps, eng.last_shape))
+            outs.append(eng.download())
+    assert shapes[0][0] == 16 and shapes[1][0] == 8
+    for other, what in ((outs[1], "8-step passes"), (outs[2], "single steps")):
+        for a, b, k in zip(outs[0], other, ("Ez", "Hx", "Hy")):
+            assert np.array_equal(a, b), f"{k}: 16-step passes {shapes[0]} vs {what} at {np.argwhere(a != b)[:3]}"
+    del outs, init
+    steps, m = 120, 384
+    amps = np.array([onp.ricker_amplitude(i * DT, FC) for i in range(400, 400 + steps)])
+    with fd.Engine(r, c, DT, DX, dtype=np.float64) as eng:
+        eng.set_materials()
+        eng.run(steps, r // 2, c // 2, amps)
+        Ez, Hx, Hy = eng.download()
+    ref = onp.grid_zeros(m, m, np.float64)
+    e, mu = onp.vacuum_materials(m, m, np.float64)
+    corc.run(*ref, e, mu, DT, DX, steps, m // 2, m // 2, amps=amps)
+    for a, b in ((Ez, ref[0]), (Hx, ref[1]), (Hy, ref[2])):
+        assert np.array_equal(a[r // 2 - 60:r // 2 + 60, c // 2 - 60:c // 2 + 60], b[m // 2 - 60:m // 2 + 60, m // 2 - 60:m // 2 + 60])

@@ -41,6 +41,9 @@ DT, DX = 5e-14, 1e-4
     (3, (105, 300), "float32", "uniform", True, {"max_pass_steps": 16, "loop": "c", "expect_overlap": False}),
     (3, (108, 300), "float32", "array", True, {"max_pass_steps": 16, "expect_overlap": False}),
     (3, (111, 300), "float32", "uniform", True, {"max_pass_steps": 16, "loop": "c", "expect_overlap": True}),
+    # float64 on 16-step cycles (round 3: the reference's dtype has the 16-step kernel too)
+    (2, (170, 600), "float64", "array", True, {"max_pass_steps": 16, "loop": "c"}),
+    (3, (300, 700), "float64", "uniform", True, {"max_pass_steps": 16}),
 ])
 def test_gpu_slabs_match_single_engine_and_oracle(tmp_path, world, shape, dtype, materials, overlap,
                                                   options):

@@ -79,6 +79,8 @@ SIGNATURES = {
     "fdtd2d_slab_detach": (_i, [_vp]),
     "fdtd2d_slab_ranks": (_ll, [_vp]),
     "fdtd2d_run_slab": (_i, [_vp, _i, _i, _i, _i, _i, C.POINTER(_d)]),
+    "fdtd2d_set_dft": (_i, [_vp, _i, _i, _i, _i, _i, C.POINTER(_d), _i]),
+    "fdtd2d_read_dft": (_i, [_vp, C.POINTER(_d), C.POINTER(_d)]),
     "fdtd2d_snapshot_index": (_i, [_vp, _d, _d, _i, _vp]),
     "fdtd2d_reduce": (_i, [_vp, _i, C.POINTER(_d), C.POINTER(_d)]),
     "fdtd2d_timer_start": (_i, [_vp]),

@@ -11,6 +11,7 @@
 #include <map>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -65,6 +66,15 @@ struct fdtd2d {
     long long probe_cap = 0, probe_step0 = 0;
     double *probe_dev = nullptr;
     bool probe_pending = false;       // the next launch_pass records this pass's steps
+    // running Fourier transform (fdtd2d_set_dft): window, frequencies, accumulators re[k][cell], im[k][cell]
+    int dft_row0 = 0, dft_col0 = 0, dft_rows = 0, dft_cols = 0, dft_n = 0, dft_every = 0;
+    double dft_omega[16] = {};
+    double *dft_acc = nullptr;
+    long long dft_step0 = 0;
+    int dft_lo() const { return std::max(dft_row0, row0); }                               // owned window rows
+    int dft_hi() const { return std::min(dft_row0 + dft_rows, row0 + nrows); }
+    // steps until the next sampled step (a large number without a transform)
+    int dft_gap() const { return dft_n ? dft_every - (int)((step - dft_step0) % dft_every) : (1 << 30); }
     int src_rows = 1, src_cols = 1;   // extent of the source: (row, col) of run/add_point is its first cell
     // a pass issued in pieces (fdtd2d_pass_rows) and not yet committed
     int pend_nt = 0;

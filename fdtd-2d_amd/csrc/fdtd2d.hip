@@ -335,6 +335,31 @@ int probe_after_step(fdtd2d *h)
     return 0;
 }
 
+// the running Fourier transform: one sample if the step that just finished is a sampled one
+int dft_after_step(fdtd2d *h)
+{
+    if (!h->dft_n || (h->step - h->dft_step0) % h->dft_every != 0) return 0;
+    const int lo = h->dft_lo(), hi = h->dft_hi();
+    if (hi <= lo) return 0;
+    if (lo < h->ev.lo || hi > h->ev.hi) return fail(h, FDTD2D_E_STATE, "the transform's window rows are not current");
+    fdtd::DftPhasors ph;
+    const double t = (double)h->step * h->dt;
+    for (int k = 0; k < h->dft_n; ++k) {
+        ph.c[k] = std::cos(h->dft_omega[k] * t);
+        ph.s[k] = -std::sin(h->dft_omega[k] * t);
+    }
+    const size_t cells = (size_t)(hi - lo) * h->dft_cols;
+    const unsigned blocks = (unsigned)std::min<size_t>((cells + 255) / 256, 4096);
+    if (h->dtype == FDTD2D_F32)
+        hipLaunchKernelGGL((fdtd::k_dft<float>), dim3(blocks), dim3(256), 0, h->stream, (const float *)h->ez[h->cur], h->geom(), lo,
+                           hi - lo, h->dft_col0, h->dft_cols, h->dft_n, ph, h->dft_acc);
+    else
+        hipLaunchKernelGGL((fdtd::k_dft<double>), dim3(blocks), dim3(256), 0, h->stream, (const double *)h->ez[h->cur], h->geom(), lo,
+                           hi - lo, h->dft_col0, h->dft_cols, h->dft_n, ph, h->dft_acc);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
 int do_add_point(fdtd2d *h, int row, int col, double amp)
 {
     if (row < 0 || row + h->src_rows > h->rows || col < 0 || col + h->src_cols > h->cols)
@@ -636,6 +661,7 @@ void fdtd2d_destroy(fdtd2d_t *h)
         if (h->scratch) (void)hipFree(h->scratch);
         if (h->trash) (void)hipFree(h->trash);
         if (h->probe_dev) (void)hipFree(h->probe_dev);
+        if (h->dft_acc) (void)hipFree(h->dft_acc);
         if (h->clk_dev) (void)hipFree(h->clk_dev);
         if (h->clk_stream) { (void)hipStreamSynchronize(h->clk_stream); (void)hipStreamDestroy(h->clk_stream); }
         if (h->side_stream) { (void)hipStreamSynchronize(h->side_stream); (void)hipStreamDestroy(h->side_stream); }
@@ -880,6 +906,47 @@ int fdtd2d_read_probe(fdtd2d_t *h, double *out, long long first, long long count
     if (rc) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (count) HIPCHK(h, hipMemcpy(out, h->probe_dev + first, (size_t)count * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int fdtd2d_set_dft(fdtd2d_t *h, int row0, int col0, int nrows, int ncols, int nfreq, const double *omega, int every)
+{
+    if (!h) return FDTD2D_E_ARG;
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (h->pend_nt) return fail(h, FDTD2D_E_STATE, "a partial pass is pending: commit it first");
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->dft_acc) { (void)hipFree(h->dft_acc); h->dft_acc = nullptr; }
+    h->dft_n = 0;
+    if (nfreq == 0) return 0;
+    if (nfreq < 0 || nfreq > 16 || !omega || every < 1 || nrows < 1 || ncols < 1 || row0 < 0 || col0 < 0 ||
+        row0 + nrows > h->rows || col0 + ncols > h->cols)
+        return fail(h, FDTD2D_E_ARG, "need 1..16 frequencies, every >= 1 and a window inside the %dx%d grid", h->rows, h->cols);
+    h->dft_row0 = row0; h->dft_col0 = col0; h->dft_rows = nrows; h->dft_cols = ncols; h->dft_every = every;
+    for (int k = 0; k < nfreq; ++k) h->dft_omega[k] = omega[k];
+    h->dft_step0 = h->step;
+    const size_t own = (size_t)std::max(0, h->dft_hi() - h->dft_lo()) * ncols;
+    if (own) {
+        if (hipMalloc((void **)&h->dft_acc, own * 2 * nfreq * sizeof(double)) != hipSuccess)
+            return fail(h, FDTD2D_E_NOMEM, "hipMalloc of the transform's accumulators failed");
+        HIPCHK(h, hipMemsetAsync(h->dft_acc, 0, own * 2 * nfreq * sizeof(double), h->stream));
+    }
+    h->dft_n = nfreq;
+    return 0;
+}
+
+int fdtd2d_read_dft(fdtd2d_t *h, double *re, double *im)
+{
+    if (!h || !re || !im) return FDTD2D_E_ARG;
+    if (!h->dft_n) return fail(h, FDTD2D_E_STATE, "no transform is set");
+    int rc = use_device(h);
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const size_t own = (size_t)std::max(0, h->dft_hi() - h->dft_lo()) * h->dft_cols;
+    for (int k = 0; k < h->dft_n && own; ++k) {
+        HIPCHK(h, hipMemcpy(re + (size_t)k * own, h->dft_acc + (size_t)(2 * k) * own, own * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHK(h, hipMemcpy(im + (size_t)k * own, h->dft_acc + (size_t)(2 * k + 1) * own, own * sizeof(double), hipMemcpyDeviceToHost));
+    }
     return 0;
 }
 
@@ -1246,7 +1313,7 @@ int fdtd2d_run(fdtd2d_t *h, int nsteps, int src_row, int src_col, const double *
     int n = 0;
     while (n < nsteps) {
         int nt = 0, nlev = 0, lo = 0, hi = 0;
-        if (plan_pass(h, nsteps - n, &nt, &nlev, &lo, &hi)) {
+        if (plan_pass(h, std::min(nsteps - n, h->dft_gap()), &nt, &nlev, &lo, &hi)) {
             const double *a = amps ? amps + n : nullptr;
             // (only full passes are tuned: a one-off tail does not pay for 20-120 ms of trial launches;
             // it uses the shape measured for full passes of its kernel if there is one)
@@ -1256,6 +1323,7 @@ int fdtd2d_run(fdtd2d_t *h, int nsteps, int src_row, int src_col, const double *
                      ? launch_pass<float>(h, nt, lo, hi, src_row, src_col, a, h->top(), h->bottom(), true, lo, hi, nlev)
                      : launch_pass<double>(h, nt, lo, hi, src_row, src_col, a, h->top(), h->bottom(), true, lo, hi, nlev);
             if (rc) return rc;
+            if ((rc = dft_after_step(h))) return rc;
             n += nlev;
             continue;
         }
@@ -1263,6 +1331,7 @@ int fdtd2d_run(fdtd2d_t *h, int nsteps, int src_row, int src_col, const double *
         if ((rc = do_update_e(h))) return rc;
         if (amps && (rc = do_add_point(h, src_row, src_col, amps[n]))) return rc;
         if ((rc = probe_after_step(h))) return rc;
+        if ((rc = dft_after_step(h))) return rc;
         ++n;
     }
     return 0;
@@ -1339,7 +1408,7 @@ int fdtd2d_pass_commit(fdtd2d_t *h)
     h->step += nt;
     h->pend_nt = 0;
     h->pend_done.clear();
-    return 0;
+    return dft_after_step(h);
 }
 
 double fdtd2d_source_amplitude(int src_kind, double t, double fc)

@@ -88,4 +88,23 @@ template <class T> __global__ void k_probe_copy(const T *ez, size_t off, double 
     out[idx] = (double)ez[off];
 }
 
+// one sample of the running Fourier transform: acc_re[k][cell] += Ez * c[k], acc_im[k][cell] += Ez * s[k]
+struct DftPhasors {
+    double c[16], s[16];
+};
+template <class T>
+__global__ __launch_bounds__(256) void k_dft(const T *__restrict__ ez, Geom g, int row_lo, int nrows, int col0, int ncols,
+                                              int nfreq, DftPhasors ph, double *__restrict__ acc)
+{
+    const size_t cells = (size_t)nrows * ncols, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t n = (size_t)blockIdx.x * blockDim.x + threadIdx.x; n < cells; n += stride) {
+        const int i = row_lo + (int)(n / ncols), j = col0 + (int)(n % ncols);
+        const double e = (double)ez[at(g, i, j)];
+        for (int k = 0; k < nfreq; ++k) {
+            acc[(size_t)(2 * k) * cells + n] += e * ph.c[k];
+            acc[(size_t)(2 * k + 1) * cells + n] += e * ph.s[k];
+        }
+    }
+}
+
 }  // namespace fdtd

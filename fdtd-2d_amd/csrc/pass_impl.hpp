@@ -110,9 +110,11 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
                 HIPCHK(h, hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
                 bool wide = false;
                 if constexpr (NT > 16 && sizeof(T) == 4) {
-                    // 128-column tiles (dynamic LDS: 95 KB) on grids of 8192 columns and more, ZoneDims
+                    // 128-column LDS tiles (dynamic LDS: 95 KB) on grids of 16384 columns and more (ZoneDims); below that
+                    // the register-resident tiles of kernels_zone.hpp (round 3: run(20) at 8192^2 0.555 vs 0.585 ms,
+                    // equal at 16384^2)
                     using DW = fdtd::ZoneDims<NT, true>;
-                    if (h->cols >= 8192) {
+                    if (h->cols >= 16384) {
                         wide = true;
                         constexpr size_t zone_dyn = (size_t)DW::LDS_ELEMS * sizeof(T);
                         // (every time: the attribute belongs to the device's code object, and a 20-step pass is a

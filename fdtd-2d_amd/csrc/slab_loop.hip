@@ -320,6 +320,8 @@ int fdtd2d_run_slab(fdtd2d_t *h, int nsteps, int cycle, int overlap, int src_row
     if (!s) return fail(h, FDTD2D_E_STATE, "no slab loop attached: call fdtd2d_slab_attach[_rccl] first");
     if (nsteps < 0 || cycle < 1 || cycle > h->halo)
         return fail(h, FDTD2D_E_ARG, "need nsteps >= 0 and 1 <= cycle <= halo (%d)", h->halo);
+    if (h->dft_n && h->dft_every % cycle != 0)
+        return fail(h, FDTD2D_E_ARG, "a running Fourier transform samples every %d steps: not a multiple of the %d-step cycle", h->dft_every, cycle);
     if (hipSetDevice(h->device) != hipSuccess) return fail(h, FDTD2D_E_NODEVICE, "hipSetDevice failed");
     // Overlapped cycles need a temporally blocked pass of `cycle` steps.  Only quantities every rank
     // shares enter this decision (whether EVERY slab is tall enough for two edge pieces and an

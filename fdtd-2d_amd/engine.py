@@ -253,6 +253,26 @@ class Engine:
         self._ck(self._lib.fdtd2d_read_probe(self._h, out.ctypes.data, int(first), int(count)))
         return out
 
+    def set_dft(self, window, omegas, every=16):
+        """Running Fourier transform of Ez: window = (row0, col0, nrows, ncols); omegas = angular
+        frequencies (at most 16); after every `every`-th step n the engine adds Ez * exp(-1j * omega * n * dt) per cell
+        and frequency (float64, on the device).  every = 16 rides on the 16-step passes for free.  omegas = () removes it."""
+        w = np.ascontiguousarray(omegas, dtype=np.float64).reshape(-1)
+        r0, c0, nr, nc = (int(v) for v in window)
+        self._ck(self._lib.fdtd2d_set_dft(self._h, r0, c0, nr, nc, int(w.size), w.ctypes.data_as(C.POINTER(C.c_double)), int(every)))
+        lo, hi = max(r0, self.row0), min(r0 + nr, self.row0 + self.nrows)
+        self._dft = (int(w.size), max(0, hi - lo), nc)
+        return self
+
+    def read_dft(self):
+        """complex128 array (frequencies, owned window rows, window columns) of the accumulated transform."""
+        nf, nr, nc = getattr(self, "_dft", (0, 0, 0))
+        re, im = np.zeros((nf, nr, nc)), np.zeros((nf, nr, nc))
+        if nf:
+            self._ck(self._lib.fdtd2d_read_dft(self._h, re.ctypes.data_as(C.POINTER(C.c_double)),
+                                               im.ctypes.data_as(C.POINTER(C.c_double))))
+        return re + 1j * im
+
     def set_source_extent(self, nrows=1, ncols=1):
         """Line / patch sources: the source of add_point / run / pass_rows becomes the rectangle
         of nrows x ncols cells starting at the (row, col) given there (default one cell)."""

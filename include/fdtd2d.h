@@ -320,6 +320,17 @@ int fdtd2d_run_slab(fdtd2d_t *h, int nsteps, int cycle, int overlap, int src_row
 
 /* ---- consumers of Ez next to the loop ---------------------- */
 
+/* Running Fourier transform of Ez at given angular frequencies over a window of cells (the data
+ * that connects the time-domain loop to the reference's frequency-domain fields, fdfd.py:111-118).  From this call on, after
+ * every `every`-th completed step n (counted by fdtd2d_info(STEP)) the engine adds Ez[i,j] * exp(-i * omega_k * n * dt) to
+ * accumulator k of every cell of the window [row0, row0+nrows) x [col0, col0+ncols) (float64 accumulation on the device; a
+ * slab accumulates the window rows it owns).  While a transform is set the loop cuts its temporally blocked passes at the
+ * sampled steps (every = 16 costs nothing, every = 1 runs single steps); fdtd2d_run_slab needs `every` to be a multiple of
+ * its cycle.  nfreq <= 16.  nfreq = 0 removes it.  fdtd2d_read_dft copies the accumulators: re and im, each nfreq x (owned
+ * window rows) x ncols float64, row-major; synchronous. */
+int fdtd2d_set_dft(fdtd2d_t *h, int row0, int col0, int nrows, int ncols, int nfreq, const double *omega, int every);
+int fdtd2d_read_dft(fdtd2d_t *h, double *re, double *im);
+
 /* Device-side first half of capture_snapshot (main.py:153-179): clip Ez to [vmin,vmax], map
  * to the 0..255 colour-map index exactly as `cmap((normed - vmin)/(vmax - vmin))` does for an
  * array of the engine's type, keep every `stride`-th row and column (global indices that are

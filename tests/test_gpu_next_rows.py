@@ -145,3 +145,49 @@ def test_probe_time_series_matches_oracle(tag, dtype, probe, max_steps):
     assert got.shape == (n - 3,) and np.array_equal(got, np.array(want[3:]))
     for a, b in zip(fields, ref):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("tag,dtype", [("f32", np.float32), ("f64", np.float64)])
+@pytest.mark.parametrize("every,max_steps", [(16, 16), (4, 16), (7, 8), (1, 16), (16, 0)])
+def test_running_fourier_transform_matches_oracle(tag, dtype, every, max_steps):
+    """N4: the running transform of Ez at two frequencies over a window, sampled every `every` steps (the loop cuts its
+    passes at the sampled steps: 16-step passes for every = 16, short passes of 4 and 7 levels, single steps), against the
+    same sum over the oracle's Ez sequence in float64: relative 1e-12 (the only difference is libm's cos / sin vs NumPy's).
+    The fields themselves stay value-identical."""
+    import fdtd2d_amd as fd
+    from oracle import fdtd_numpy as onp
+    r, c, n = 150, 300, 80
+    rng = np.random.default_rng(every * 10 + max_steps)
+    Ez = rng.standard_normal((r, c)).astype(dtype)
+    Hx = (rng.standard_normal((r, c - 1)) * 1e-3).astype(dtype)
+    Hy = (rng.standard_normal((r - 1, c)) * 1e-3).astype(dtype)
+    eps = (onp.EPS0 * rng.uniform(1, 10, (r, c))).astype(dtype)
+    mu = np.full((r, c), onp.MU0, dtype)
+    amps = rng.standard_normal(n)
+    win = (3, 250, 60, 45)                                # reaches into the top zone and across a strip seam
+    om = 2 * np.pi * np.array([30e9, 47e9])
+    want = np.zeros((2, win[2], win[3]), np.complex128)
+
+    def on_step(i, E, *_):
+        k = i + 1
+        if k % every == 0:
+            w = E[win[0]:win[0] + win[2], win[1]:win[1] + win[3]].astype(np.float64)
+            for f in range(2):
+                want[f] += w * np.cos(om[f] * (k * 5e-14)) + 1j * (w * -np.sin(om[f] * (k * 5e-14)))
+    ref = [a.copy() for a in (Ez, Hx, Hy)]
+    onp.leapfrog(*ref, eps, mu, 5e-14, 1e-4, n, 70, 260, amps=amps, on_step=on_step)
+    with fd.Engine(r, c, 5e-14, 1e-4, dtype=dtype) as eng:
+        eng.set_materials(eps, mu).set_option(max_pass_steps=max_steps)
+        eng.upload(Ez, Hx, Hy)
+        eng.set_dft(win, om, every)
+        eng.run(50, 70, 260, amps[:50])
+        eng.run(30, 70, 260, amps[50:])
+        got = eng.read_dft()
+        fields = eng.download()
+        with pytest.raises(fd.Fdtd2dError):
+            eng.set_dft((140, 0, 20, 10), om, 4)            # window leaves the grid
+        eng.set_dft(win, (), 1)                             # removes it
+    for a, b in zip(fields, ref):
+        assert np.array_equal(a, b)
+    assert got.shape == want.shape and np.abs(want).max() > 0
+    assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max(), np.abs(got - want).max() / np.abs(want).max()

@@ -372,11 +372,12 @@ def test_full_size_config3_ring(fd, onp, corc):
         assert np.array_equal(a[sr - 80:sr + 80, sc - 80:sc + 80], b[h - 80:h + 80, h - 80:h + 80])
 
 
-@pytest.mark.parametrize("kind,shape,n,passes", [("eps", (2100, 8200), 35, 2), ("eps+mu", (1500, 8192), 20, 1),
-                                                 ("mu", (1203, 9001), 17, 1)])
+@pytest.mark.parametrize("kind,shape,n,passes", [("eps", (1100, 16400), 35, 2), ("eps+mu", (800, 16384), 20, 1),
+                                                 ("mu", (603, 17001), 17, 1), ("eps", (2100, 8200), 35, 2)])
 def test_wide_zone_tiles_with_array_materials_vs_c_oracle(fd, onp, corc, kind, shape, n, passes):
     """k_zone<float, 20, CE_ARR / CH_ARR, WIDE> -- the 128-column dynamic-LDS zone tiles the 20-step pass uses from
-    8192 columns up -- with coefficient arrays (round-2 verdict: never compared with anything).  Whole grids from a
+    16384 columns up (8192 until the register-resident tiles took over below that) -- with coefficient arrays
+    (round-2 verdict: never compared with anything); the 8200-column case runs the register tiles with arrays.  Whole grids from a
     random state with random eps / mu, the point source on the last row of the 25-row top zone; 35 steps = a 16-step
     pass + a 19-step remainder on the 20-step kernel, 20 and 17 steps = one such pass.  Every cell equals the C
     oracle (the reference's sequential boundary order, pinned to the golden vectors) and the single-step kernels."""
@@ -405,7 +406,8 @@ def test_wide_zone_tiles_with_array_materials_vs_c_oracle(fd, onp, corc, kind, s
 
 def test_full_size_config3_ring_20_step_remainder(fd, onp, corc):
     """BASELINE configs[2]'s own grid (8192^2, ring-resonator eps array) with a step count that ends in a 17..20-step
-    remainder: 36 = 16 + 20, the second pass on k_bulk_split<float, 20, ..., CE_ARR> + the wide array zone tiles.
+    remainder: 36 = 16 + 20, the second pass on k_bulk_split<float, 20, ..., CE_ARR> + its zone tiles with an eps array
+    (the register-resident tiles below 16384 columns; the 128-column LDS tiles are covered at 16384+ columns above).
     Passes equal the single-step kernels on every cell from a random state; and from zero fields the window
     around the source equals the C oracle on the sub-grid with the same local eps."""
     n = 8192

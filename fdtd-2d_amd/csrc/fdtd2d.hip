@@ -1078,7 +1078,7 @@ static int tune_pass(fdtd2d *h, int nt, int lo, int hi, bool zt, bool zb, int sr
             const int zones = (zone_tiles + tpw - 1) / tpw;
             const double fill = 2.0 * nt + nw - 1;
             for (int k : {1, 2, 3, 4}) {
-                for (double w_e : {1.0, 2.0, 3.0}) {            // edge bands as tall, 1/2, 1/3 as long-lived
+                for (double w_e : {1.0, 1.5, 2.0, 3.0}) {            // edge bands as tall, 1/2, 1/3 as long-lived
                     const double tasks = (double)k * slots - (k == 1 ? zones : 0);
                     fdtd2d::Shape best{0, 0};
                     for (int nb = 1; nb <= region / 8; ++nb) {
@@ -1100,7 +1100,7 @@ static int tune_pass(fdtd2d *h, int nt, int lo, int hi, bool zt, bool zb, int sr
                 const int n_i = std::max(1, ns - 2 - n_src), nshort = zones / n_i;
                 for (int tz : {32, 48, 64, 80, 96, 112}) {
                     if (k != 1 || zones == 0 || sd != 1 || nshort < 1) break;
-                    for (double w_e : {1.0, 2.0, 3.0}) {
+                    for (double w_e : {1.0, 1.5, 2.0, 3.0}) {
                         fdtd2d::Shape best{0, 0};
                         for (int nl = 1; nl <= region / 8; ++nl) {
                             const int rl = (region + nshort * tz + nl + nshort - 1) / (nl + nshort);     // rows of a tall band

@@ -15,7 +15,7 @@ import numpy as np
 
 
 def run_local_slabs(fd, world, shape, dtype, boundary, st, nsteps, src, *, cycle_opt=None, overlap=True,
-                    materials="array", extent=None, pml=None):
+                    materials="array", extent=None, pml=None, options=None):
     """Returns (Ez, Hx, Hy) of the whole grid assembled from the ranks' owned rows, plus the cycle used.
     st: dict with full-grid Ez, Hx, Hy, eps, mu, amps (float64; cast here)."""
     import hipmem
@@ -37,6 +37,8 @@ def run_local_slabs(fd, world, shape, dtype, boundary, st, nsteps, src, *, cycle
             eng.set_pml(**(pml or {}))
         if cycle_opt is not None:
             eng.set_option(max_pass_steps=cycle_opt)
+        if options:
+            eng.set_option(**options)
         if extent:
             eng.set_source_extent(*extent)
         eng.upload(st["Ez"][r0:r1].astype(dt_), st["Hx"][r0:r1].astype(dt_),

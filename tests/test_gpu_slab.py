@@ -288,3 +288,25 @@ def test_c_loop_refuses_overlap_on_slabs_that_cut_the_zone():
         with pytest.raises(_abi.Fdtd2dError) as e:
             eng.run_slab(16, 16, True)
         assert e.value.code == _abi.E_ARG and not called
+
+
+@pytest.mark.parametrize("side,xcd,materials", [(2, 0, "uniform"), (2, 1, "array"), (4, 1, "uniform")])
+def test_slabs_with_strips_of_several_waves(side, xcd, materials):
+    """The launch shapes round 3 added -- 2 / 4 waves side by side per level group, tasks dealt out XCD by XCD -- inside a
+    row-slab run (pieces of a pass next to the cuts, interior piece, overlapped 16-step cycles): 3 slabs of a 240-row
+    grid wide enough for them, equal to the oracle bit for bit."""
+    import fdtd2d_amd as fd
+    from oracle import fdtd_numpy as onp
+    from local_slabs import run_local_slabs
+    world, r, c, n = 3, 240, 4200 * (2 if side == 4 else 1), 35
+    st = _slab_state(r, c, n, side + xcd)
+    if materials == "uniform":
+        st["eps"][:] = 2.5 * onp.EPS0
+    src = (80, 251)
+    got, cycle, overlapped, launches = run_local_slabs(fd, world, (r, c), np.float32, "mur", st, n, src, cycle_opt=16,
+                                                       materials=materials, options=dict(side_waves=side, xcd_map=xcd))
+    assert cycle == 16 and overlapped and min(launches) > 0
+    ref = [st[k].astype(np.float32) for k in ("Ez", "Hx", "Hy")]
+    onp.leapfrog(*ref, st["eps"].astype(np.float32), st["mu"].astype(np.float32), DT, DX, n, src[0], src[1], amps=st["amps"])
+    for a, b, k in zip(got, ref, ("Ez", "Hx", "Hy")):
+        assert np.array_equal(a, b), f"{k}: slabs (side {side}, xcd {xcd}) differ from the oracle at {np.argwhere(a != b)[:3]}"

@@ -9,6 +9,11 @@ grid = int(sys.argv[1]); mat = sys.argv[2] if len(sys.argv) > 2 else "uniform"; 
 eng = bench.make_engine(fd, grid, grid, mat, 0, "mur")
 cyc = eng.cycle_steps
 eng.run(64, grid // 2, grid // 2, bench.amplitudes(fd, 0, 64)).sync()
+if os.environ.get("AB_RANDOM_FIELDS"):      # data in every cell: the chip holds a lower clock (profiles/r03_clock_vs_launch.txt)
+    eng.upload(bench.hash_rows(0, grid, grid, 1, 1.0), bench.hash_rows(0, grid, grid, 2, 1e-3)[:, :grid - 1],
+               bench.hash_rows(0, grid - 1, grid, 3, 1e-3))
+    eng.run(32).sync()
+    print("pseudo-random fields in every cell", flush=True)
 combos = [(1, 0), (1, 1), (2, 0), (2, 1)] + ([(4, 0), (4, 1)] if mat == "uniform" else [])
 for r in range(rounds):
     for sd, xc in combos:

@@ -42,7 +42,9 @@ roofline = the kernels that produced `value` (the passes of ONE run of K steps; 
   algorithmic              SURVEY.md section 8 M2's figure (24 B per cell-step, +4 per coefficient array)
                            x cells x K / run time, and its ratio to 8.0 TB/s (> 1 means: fewer real bytes
                            than a one-step-per-pass kernel must move).
-  steady_state             the full-length pass kernel (16 steps; 8 for float64) by itself: trimmed mean of
+  frac_of_copy_rate        achieved / what a plain 16-byte-per-lane copy of the same field arrays reaches on this box in
+                           this run (copy_kernel_GBps_before_after): the practical ceiling beside the data sheet's.
+  steady_state             the full-length pass kernel (16 steps) by itself: trimmed mean of
                            48 back-to-back launches, each between its own pair of HIP events on the engine's
                            stream (what rocprofv3's kernel trace reports per dispatch), with its own traffic.
 gpu_state = clocks per XCD, memory clock, socket power, temperature and the throttle-residency counters read
@@ -521,7 +523,15 @@ def single_record(fd, rows, cols, steps, warmup, materials, boundary, device, pm
                                   + " boundary, ricker point source at the centre" + note,
                       "grid": [rows, cols], "materials": materials, "boundary": boundary},
            "roofline": roofline_block(cells, steps, r, traffic)}
-    rec["roofline"]["copy_kernel_GBps_before_after"] = r["copy_gbps"]
+    rl = rec["roofline"]
+    rl["copy_kernel_GBps_before_after"] = r["copy_gbps"]
+    # the same rates against what a plain copy of the same arrays reaches on this box (the practical ceiling)
+    copy = max(r["copy_gbps"]) if r["copy_gbps"] else 0
+    if copy > 0:
+        if rl.get("achieved"):
+            rl["frac_of_copy_rate"] = round(rl["achieved"] / copy, 4)
+        if rl.get("steady_state", {}).get("achieved"):
+            rl["steady_state"]["frac_of_copy_rate"] = round(rl["steady_state"]["achieved"] / copy, 4)
     if "gpu_during" in r:
         rec["gpu_during"] = r["gpu_during"]
     if "clock_vs_launch" in r:

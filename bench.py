@@ -678,6 +678,24 @@ def main():
                 except Exception as exc:
                     t = f"live PMC failed ({exc})"
             traffic.append(t)
+        # the tolerance build (libfdtd2d_fused.so: multiply-add pairs as FMA) on the headline workload: a child process
+        # with FDTD2D_ARITHMETIC=fused -- the library is chosen at import --, also started before this process
+        # touches the GPU
+        fused_rec = None
+        if default_cfg and not args.no_secondary and os.environ.get("FDTD2D_ARITHMETIC", "exact") == "exact" and \
+                os.path.exists(os.path.join(ROOT, "fdtd-2d_amd", "libfdtd2d_fused.so")):
+            try:
+                cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(args.steps), "--warmup", str(args.warmup),
+                       "--repeats", str(args.repeats), "--pmc", args.pmc, "--no-secondary", "--no-cpu-baseline"]
+                p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, FDTD2D_ARITHMETIC="fused"))
+                d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+                fused_rec = {k: d[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "repeats", "value_min_max", "roofline")}
+                fused_rec["dtype"] = "f32"
+                fused_rec["arithmetic"] = "fused multiply-add (libfdtd2d_fused.so, FDTD2D_ARITHMETIC=fused): within the stated " \
+                                          "float32 tolerance of the reference, not value-identical (tests/test_fused_build.py)"
+                fused_rec["config"] = dict(d["config"], workload=d["config"]["workload"] + " -- tolerance build")
+            except Exception as exc:
+                fused_rec = {"arithmetic": "fused", "error": f"{type(exc).__name__}: {exc}"}
         gpu = GpuState(local)
         before = gpu.read()
         import torch
@@ -699,10 +717,12 @@ def main():
                "roofline": head["roofline"],
                "gpu_state": {"source": "amdsmi gpu_metrics", "partition": getattr(gpu, "partition", None),
                              "before": before, "during_timed_region": head.get("gpu_during"), "after": gpu.read()}}
-        if len(out) > 1:
+        if len(out) > 1 or fused_rec:
             for o in out[1:]:
                 o.pop("wall_ms_all", None)
-            res["secondary"] = out[1:]
+            res["secondary"] = out[1:] + ([fused_rec] if fused_rec else [])
+        res["arithmetic"] = os.environ.get("FDTD2D_ARITHMETIC", "exact") + \
+            (" (one rounding per operation: value-identical to the reference)" if os.environ.get("FDTD2D_ARITHMETIC", "exact") == "exact" else "")
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(rows)
         print(json.dumps(res))

@@ -298,6 +298,8 @@ __device__ __forceinline__ void split_body(const PassParams<T> &p, const int str
             }
         }
     };
+    // (Measured and rejected, profiles/r03_rejected.txt: s_setprio 3 for the loading wave, the one the others wait for at the
+    // tick barrier -- 127.5 vs 126.5-132 us at 4096^2, 366 vs 364 at 8192^2, 1308 vs 1302-1320 at 16384^2: nothing.)
     if (ROLE == 0) {
 #pragma unroll
         for (int k = 0; k < PF; ++k) load_global(slot[k], tau0 + k);

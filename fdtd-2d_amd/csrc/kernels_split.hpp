@@ -298,7 +298,8 @@ __device__ __forceinline__ void split_body(const PassParams<T> &p, const int str
             }
         }
     };
-    // (Measured and rejected, profiles/r03_rejected.txt: s_setprio 3 for the loading wave, the one the others wait for at the
+    // (Measured and rejected, profiles/r03_rejected.txt: 2 waves x 8 levels -- half the hand-offs, 6 workgroups per CU at 3 waves
+    // per SIMD: 1420 vs 1295 us at 16384^2, 440 vs 366 at 8192^2, 153 vs 126 at 4096^2 -- and s_setprio 3 for the loading wave, the one the others wait for at the
     // tick barrier -- 127.5 vs 126.5-132 us at 4096^2, 366 vs 364 at 8192^2, 1308 vs 1302-1320 at 16384^2: nothing.)
     if (ROLE == 0) {
 #pragma unroll

@@ -1072,9 +1072,9 @@ static int tune_pass(fdtd2d *h, int nt, int lo, int hi, bool zt, bool zb, int sr
             if (nw == 8 && (!both_nw || sd > 1)) continue;
             // resident workgroups (VGPR / LDS limits): 16 waves per CU
             const int slots = 256 * (nw == 8 ? 2 : 4) / sd;
-            // workgroups of the fused zone tiles: float32 16-step passes keep a tile in the registers of two waves
-            // (kernels_zone.hpp), nw / 2 tiles per workgroup; the LDS tiles take a workgroup each
-            const int tpw = (h->dtype == FDTD2D_F32 && nt >= 16) ? nw / 2 : 1;
+            // workgroups of the fused zone tiles: 16-step passes keep a tile in the registers of two (float32) or four
+            // (float64) waves (kernels_zone.hpp); the LDS tiles take a workgroup each
+            const int tpw = (h->dtype == FDTD2D_F32 && nt >= 16) ? nw / 2 : ((h->dtype == FDTD2D_F64 && nt == 16) ? nw / 4 : 1);
             const int zones = (zone_tiles + tpw - 1) / tpw;
             const double fill = 2.0 * nt + nw - 1;
             for (int k : {1, 2, 3, 4}) {

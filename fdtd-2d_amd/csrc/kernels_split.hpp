@@ -381,7 +381,7 @@ __global__ __launch_bounds__(64 * SPLIT_NW * SD) void k_bulk_split(const PassPar
     constexpr int NF = 3 + (CE_ARR ? 1 : 0) + (CH_ARR ? 1 : 0);
     // one LDS allocation, used either as the hand-off buffers of a strip or as a zone tile
     constexpr int HAND = (SPLIT_NW - 1) * HAND_DEPTH * NF * side_units(LV, V, SD);      // VecN units
-    constexpr int ZONE_ELEMS = zone_in_registers<T, NT>() ? zone_tiles_per_wg<64 * SPLIT_NW>() * 128 : ZoneDims<NT>::LDS_ELEMS;
+    constexpr int ZONE_ELEMS = zone_in_registers<T, NT>() ? zone_xch_elems<T, 64 * SPLIT_NW>() : ZoneDims<NT>::LDS_ELEMS;
     constexpr int ZONE = !FUSE ? 0 : (ZONE_ELEMS * (int)sizeof(T) + (int)sizeof(VecN<T, V>) - 1) / (int)sizeof(VecN<T, V>);
     // (several waves side by side: the joint rows can exceed the 64 KB a static allocation may have)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];

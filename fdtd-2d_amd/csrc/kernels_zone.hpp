@@ -1,4 +1,5 @@
-// Register-resident zone tiles (round 3): the top / bottom ZO = 5 + NT rows of a 16- or 20-step float32 pass.
+// Register-resident zone tiles (round 3): the top / bottom ZO = 5 + NT rows of a 16- or 20-step float32 pass and of a
+// 16-step float64 pass (four waves per tile there: a float64 row takes two registers per value).
 //
 // zone_body (kernels_stream.hpp) keeps a tile in LDS and sends every cell of every step through it: ~40 k
 // wave-instructions per 64-column tile and 16 steps, with four waves that share a CU with three other workgroups -- at
@@ -23,18 +24,24 @@
 namespace fdtd {
 
 // which passes take their zone tiles from registers
-template <class T, int NT, bool WIDE = false> constexpr bool zone_in_registers() { return sizeof(T) == 4 && NT >= 16 && !WIDE; }
+// (float64: 16-step passes; its rows take two registers per value, so a tile is spread over four waves)
+template <class T, int NT, bool WIDE = false> constexpr bool zone_in_registers()
+{
+    return !WIDE && (sizeof(T) == 4 ? NT >= 16 : NT == 16);
+}
+template <class T> constexpr int zone_waves() { return sizeof(T) == 4 ? 2 : 4; }       // waves per register-resident tile
 
-constexpr int ZONE_WAVES = 2;        // waves per register-resident tile
-
-// xch: 2 x 64 elements of LDS for this tile (the row of Ez handed up, the row of Hx handed down)
+// xch: 2 x 64 elements of LDS per wave of this tile (the row of Ez a wave hands up, the row of Hx it hands down);
+// `half` = the wave's place in the tile, 0 .. NQ - 1 from the top
 template <class T, int NT, bool CE_ARR, bool CH_ARR>
 __device__ __forceinline__ void zone_wave(const PassParams<T> &p, const int tile, const bool bottom, const int half,
                                           const bool active, T *xch)
 {
     using D = ZoneDims<NT>;
     static_assert(D::WL == 64, "one lane per tile column");
-    constexpr int RW = (D::ZR + 1) / 2;                     // rows per wave
+    constexpr int NQ = zone_waves<T>();
+    constexpr int RW = (D::ZR + NQ - 1) / NQ;               // rows per wave
+    static_assert(D::ZR - (NQ - 1) * RW >= 6 && RW >= 6, "the band rows and the row beyond them must sit in ONE wave");
     const Geom g = p.g;
     const int R = g.R, C = g.C;
     const int lane = threadIdx.x & 63;
@@ -74,10 +81,10 @@ __device__ __forceinline__ void zone_wave(const PassParams<T> &p, const int tile
         // rows still inside the cone of the ZO output rows (as zone_body): `keep` rows next to the grid edge
         const int keep = min(D::ZR, D::ZO + (p.nlev - step) + 2);
         const int k_lo = bottom ? D::ZR - keep : 0, k_hi = bottom ? D::ZR : keep;      // tile rows [k_lo, k_hi)
-        // ---- the lower wave hands its first row of Ez up
-        if (half == 1) xch[lane] = e[0];
+        // ---- every wave hands its first row of Ez up to the wave above
+        xch[128 * half + lane] = e[0];
         __syncthreads();
-        const T e_below = half == 0 ? xch[lane] : e[RW - 1];
+        const T e_below = half + 1 < NQ ? xch[128 * (half + 1) + lane] : e[RW - 1];
         // ---- H half-step (main.py:66-76)
 #pragma unroll
         for (int r = 0; r < RW; ++r) {
@@ -88,10 +95,10 @@ __device__ __forceinline__ void zone_wave(const PassParams<T> &p, const int tile
             x[r] = x[r] - ch * (en - e[r]);
             y[r] = y[r] + ch * (right - e[r]);
         }
-        // ---- the upper wave hands its last row of Hx down
-        if (half == 0) xch[64 + lane] = x[RW - 1];
+        // ---- every wave hands its last row of Hx down to the wave below (every wave but the last holds RW rows)
+        xch[128 * half + 64 + lane] = x[RW - 1];
         __syncthreads();
-        const T x_above = half == 1 ? xch[64 + lane] : x[0];
+        const T x_above = half > 0 ? xch[128 * (half - 1) + 64 + lane] : x[0];
         // ---- E half-step, rows in increasing order; a top-band row is finished one row later (it needs B of the
         // row below), a bottom-band row at once (it needs B of the row above)
         T p_prev = T(0), b_prev = T(0);
@@ -138,10 +145,10 @@ __device__ __forceinline__ void zone_wave(const PassParams<T> &p, const int tile
                 e[r] = in_l ? dl : (in_r ? dr : e[r]);
             }
         }
-        if ((has_l || has_r) && bottom && half == 1) {
+        if ((has_l || has_r) && bottom && half == NQ - 1) {
 #pragma unroll
             for (int q = 0; q < 5; ++q) {                      // rows R-1..R-5, decreasing: e[r - 1] is still its C value
-                const int r = (D::ZR - RW) - 1 - q;             // the lower wave holds ZR - RW rows
+                const int r = (D::ZR - (NQ - 1) * RW) - 1 - q;  // the last wave holds ZR - (NQ - 1) RW rows
                 const T cn = from_next(e[r]), cp = from_prev(e[r]);
                 const T dl = (e[r - 1] + cn) / T(2), dr = (e[r - 1] + cp) / T(2);
                 e[r] = in_l ? dl : (in_r ? dr : e[r]);
@@ -171,27 +178,29 @@ __device__ __forceinline__ void zone_wave(const PassParams<T> &p, const int tile
 }
 
 // The waves of a workgroup of THREADS threads take THREADS / 128 tiles; workgroup `wg` of the zone part of a launch.
-// smem: THREADS / 128 x 128 elements.
+// smem: 128 elements per wave.
 template <class T, int NT, bool CE_ARR, bool CH_ARR, int THREADS>
 __device__ __forceinline__ void zone_wave_group(const PassParams<T> &p, const int wg, T *smem)
 {
-    constexpr int TPW = THREADS / (64 * ZONE_WAVES);
+    constexpr int NQ = zone_waves<T>(), TPW = THREADS / (64 * NQ);
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int q = wid / ZONE_WAVES, half = wid - q * ZONE_WAVES;
+    const int q = wid / NQ, half = wid - q * NQ;
     const int total = (p.zone_top + p.zone_bot) * p.zone_tiles;
     const int gt = wg * TPW + q;
     const bool active = gt < total;                      // (a workgroup's last tiles may not exist: they run along for the
     const int gtc = min(gt, total - 1);                  // barriers and store nothing)
     const int z = gtc / p.zone_tiles;
-    zone_wave<T, NT, CE_ARR, CH_ARR>(p, gtc - z * p.zone_tiles, p.zone_top ? z == 1 : true, half, active, smem + q * 128);
+    zone_wave<T, NT, CE_ARR, CH_ARR>(p, gtc - z * p.zone_tiles, p.zone_top ? z == 1 : true, half, active, smem + q * (128 * NQ));
 }
 
-template <int THREADS> constexpr int zone_tiles_per_wg() { return THREADS / (64 * ZONE_WAVES); }
+template <class T, int THREADS> constexpr int zone_tiles_per_wg() { return THREADS / (64 * zone_waves<T>()); }
+// LDS elements a workgroup's register-resident tiles need
+template <class T, int THREADS> constexpr int zone_xch_elems() { return (THREADS / 64) * 128; }
 
 // workgroups the zone tiles of a launch need: one per LDS tile, one per THREADS / 128 register-resident tiles
 template <class T, int NT, int THREADS, bool WIDE = false> __host__ __device__ constexpr int zone_wgs_for(int tiles)
 {
-    return zone_in_registers<T, NT, WIDE>() ? (tiles + zone_tiles_per_wg<THREADS>() - 1) / zone_tiles_per_wg<THREADS>() : tiles;
+    return zone_in_registers<T, NT, WIDE>() ? (tiles + zone_tiles_per_wg<T, THREADS>() - 1) / zone_tiles_per_wg<T, THREADS>() : tiles;
 }
 
 // ---- the zone tiles as a launch of their own (side stream, beside the bulk) -----------------------------------------
@@ -199,7 +208,7 @@ template <class T, int NT, bool CE_ARR, bool CH_ARR, bool WIDE = false>
 __global__ __launch_bounds__(PASS_THREADS) void k_zone(const PassParams<T> p)
 {
     if constexpr (zone_in_registers<T, NT, WIDE>()) {
-        __shared__ T xch[zone_tiles_per_wg<PASS_THREADS>() * 128];
+        __shared__ T xch[zone_xch_elems<T, PASS_THREADS>()];
         zone_wave_group<T, NT, CE_ARR, CH_ARR, PASS_THREADS>(p, blockIdx.x, xch);
         return;
     }

@@ -84,7 +84,7 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
     if (xcd && NT >= 8 && h->use_level_split(NT, p.band_lo, p.band_hi) && p.nstrips - 2 - p.n_src > 0) {
         // (the zone tiles ride in front of the bulk when fused: the pad makes the first inner-strip task a multiple
         // of 8 in the index the hardware sees)
-        const bool side = zones > 0 && (h->zone_split == 1 || NT > 16 || sd > 1 || (sizeof(T) == 8 && NT == 16));
+        const bool side = zones > 0 && (h->zone_split == 1 || NT > 16 || sd > 1);
         const long long front = (side ? 0 : zones) + 2LL * p.nbands_e + (long long)p.n_src * p.nbands_s;
         p.xcd_map = 1;
         p.main_tasks = p.nbands * p.n_inner;
@@ -101,8 +101,9 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
             // k_zone on the side stream (zone_split = 1)
             // (20-step passes: 4 waves x 5 levels at 4 workgroups per CU; a fused 46-row zone tile would
             // take 48 KB of LDS from every workgroup and leave 3, so their zones always run as k_zone)
-            // (float64 16-step passes: the 38-row LDS tile is 79 KB -- k_zone with dynamic LDS beside the bulk, never fused)
-            constexpr bool big_tile = sizeof(T) == 8 && NT == 16;
+            // (an LDS tile that does not fit a static allocation would have to run as k_zone with dynamic LDS, never fused:
+            // float64 16-step passes until their tiles moved into the registers of four waves)
+            constexpr bool big_tile = !fdtd::zone_in_registers<T, NT>() && (size_t)D::LDS_ELEMS * sizeof(T) > 65536;
             const bool side = zones > 0 && (h->zone_split == 1 || NT > 16 || sd > 1 || big_tile);
             p.fused_zones = zones > 0 && !side;
             if (side) {

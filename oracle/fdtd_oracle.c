@@ -162,6 +162,12 @@ int orc_run_##SUF(T *Ez, T *Hx, T *Hy, const T *eps, const T *mu, int R, int C, 
 DEFINE_ORACLE(float, f32, sqrtf)
 DEFINE_ORACLE(double, f64, sqrt)
 
+void orc_set_threads(int n)
+{
+    extern void omp_set_num_threads(int);
+    if (n > 0) omp_set_num_threads(n);
+}
+
 int orc_num_threads(void)
 {
 #ifdef _OPENMP

@@ -294,9 +294,10 @@ def _passes_vs_steps(fd, onp, rows, cols, eps, steps, src, amps, seed):
     single-step kernels (verified against the oracle cell for cell at small sizes): every band,
     strip and zone seam of the full-size launch must leave no trace.  Returns the pass result."""
     rng = np.random.default_rng(seed)
-    init = [rng.standard_normal((rows, cols), dtype=np.float32),
-            rng.standard_normal((rows, cols - 1), dtype=np.float32) * np.float32(1e-3),
-            rng.standard_normal((rows - 1, cols), dtype=np.float32) * np.float32(1e-3)]
+    # (uniform deviates: three times faster to draw than normal ones, and these arrays have up to 268 Mi elements)
+    init = [rng.random((rows, cols), dtype=np.float32) - np.float32(0.5),
+            (rng.random((rows, cols - 1), dtype=np.float32) - np.float32(0.5)) * np.float32(2e-3),
+            (rng.random((rows - 1, cols), dtype=np.float32) - np.float32(0.5)) * np.float32(2e-3)]
     outs = []
     for max_steps in (None, 0):
         with fd.Engine(rows, cols, DT, DX, dtype=np.float32) as eng:

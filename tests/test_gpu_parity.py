@@ -289,7 +289,7 @@ def _ring_eps(onp, rows, cols, r0=0, r1=None):
     return np.where(core, 10.0 * onp.EPS0, onp.EPS0).astype(np.float32)
 
 
-def _passes_vs_steps(fd, onp, rows, cols, eps, steps, src, amps, seed):
+def _passes_vs_steps(fd, onp, rows, cols, eps, steps, src, amps, seed, mu=None):
     """The same run from the same random state with temporally blocked passes and with the
     single-step kernels (verified against the oracle cell for cell at small sizes): every band,
     strip and zone seam of the full-size launch must leave no trace.  Returns the pass result."""
@@ -304,7 +304,7 @@ def _passes_vs_steps(fd, onp, rows, cols, eps, steps, src, amps, seed):
             if eps is None:
                 eng.set_materials()
             else:
-                eng.set_materials(eps, np.float32(onp.MU0))
+                eng.set_materials(eps, np.float32(onp.MU0) if mu is None else mu)
             if max_steps is not None:
                 eng.set_option(max_pass_steps=max_steps)
             eng.upload(*init)
@@ -1038,3 +1038,14 @@ def test_full_size_float64_16384_columns(fd, onp, corc):
     corc.run(*ref, e, mu, DT, DX, steps, m // 2, m // 2, amps=amps)
     for a, b in ((Ez, ref[0]), (Hx, ref[1]), (Hy, ref[2])):
         assert np.array_equal(a[r // 2 - 60:r // 2 + 60, c // 2 - 60:c // 2 + 60], b[m // 2 - 60:m // 2 + 60, m // 2 - 60:m // 2 + 60])
+
+
+def test_full_size_eps_and_mu_arrays_16384_columns(fd, onp):
+    """The 32-B-per-cell-step configuration (eps AND mu arrays) at a width where the tuner chooses among 1 / 2 waves side
+    by side and the XCD-wise order by itself (6144 x 16384, random materials): 36 steps = a 16-step pass + a 20-step pass
+    (128-column LDS zone tiles with both arrays) from a random state equal the single-step kernels on every cell."""
+    r, c = 6144, 16384
+    rng = np.random.default_rng(32)
+    eps = (onp.EPS0 * (1 + 9 * rng.random((r, c), dtype=np.float32))).astype(np.float32)
+    mu = (onp.MU0 * (1 + 2 * rng.random((r, c), dtype=np.float32))).astype(np.float32)
+    _passes_vs_steps(fd, onp, r, c, eps, 36, (r // 2, 9000), rng.standard_normal(36), 32, mu=mu)

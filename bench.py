@@ -96,6 +96,20 @@ class GpuState:
             self.h = hs[min(device, len(hs) - 1)]
             self.partition = (str(amdsmi.amdsmi_get_gpu_compute_partition(self.h)),
                               str(amdsmi.amdsmi_get_gpu_memory_partition(self.h)))
+            # which physical device this is (the same launch takes 1.28 ms on some devices and 1.48 ms on others at
+            # the same clocks and the same copy rate: DESIGN.md section 5.2) and the firmware it runs
+            self.device = {}
+            for name, keys in (("amdsmi_get_gpu_asic_info", ("market_name", "device_id", "rev_id", "asic_serial", "oam_id")),
+                               ("amdsmi_get_gpu_vbios_info", ("version", "build_date", "part_number")),
+                               ("amdsmi_get_gpu_device_bdf", None)):
+                try:
+                    v = getattr(amdsmi, name)(self.h)
+                    if keys is None:
+                        self.device["bdf"] = str(v)
+                    else:
+                        self.device.update({k: str(v[k]) for k in keys if k in v})
+                except Exception:
+                    pass
         except Exception as exc:     # no amdsmi / no permission: the block says so
             self.err = f"{type(exc).__name__}: {exc}"
 
@@ -105,6 +119,7 @@ class GpuState:
         m = self.smi.amdsmi_get_gpu_metrics_info(self.h)
         num = lambda v: v if isinstance(v, (int, float)) else None
         out = {"gfx_mhz": [num(v) for v in m.get("current_gfxclks", [])][:8], "uclk_mhz": num(m.get("current_uclk")),
+               "socclk_mhz": num(m.get("current_socclk")),
                "socket_w": num(m.get("current_socket_power")), "hotspot_c": num(m.get("temperature_hotspot")),
                "mem_c": num(m.get("temperature_mem")), "gfx_busy": num(m.get("average_gfx_activity")),
                "acc_n": num(m.get("accumulation_counter"))}
@@ -716,6 +731,7 @@ def main():
                "value_min_max": head["value_min_max"], "wall_ms_all": head["wall_ms_all"],
                "roofline": head["roofline"],
                "gpu_state": {"source": "amdsmi gpu_metrics", "partition": getattr(gpu, "partition", None),
+                             "device": getattr(gpu, "device", None),
                              "before": before, "during_timed_region": head.get("gpu_during"), "after": gpu.read()}}
         if len(out) > 1 or fused_rec:
             for o in out[1:]:

@@ -482,6 +482,8 @@ def roofline_block(cells, steps, r, traffic):
            "traffic_source": None, "overfetch": None, "valu_frac": None,
            "kernel": None, "kernels": None, "passes_per_run": passes, "steps_per_run": steps,
            "run_event_ms": {"median": round(ev, 5), "min": round(min(r["events_ms"]), 5), "max": round(max(r["events_ms"]), 5)},
+           # per launch: a run of K steps is `passes` passes, each one launch (plus, for 20-step passes, its zone kernel beside it)
+           "avg_launch_ms": round(ev / max(1, passes), 5), "steps_per_launch": round(steps / max(1, passes), 2),
            "launch_shape": dict(zip(SHAPE_KEYS, r["run_shape"]), pass_steps=r["run_last_nt"]),
            "algorithmic": {"bytes_per_cell_step": bpc, "bytes_per_run": int(alg_bytes),
                            "rate_GBps": round(alg_bytes / (ev * 1e-3) / 1e9, 1),

@@ -32,7 +32,7 @@ roofline = the kernels that produced `value` (the passes of ONE run of K steps; 
                            against 8.0 TB/s.  A pass keeps 16-20 time levels on chip, so the algorithmic
                            byte count of the step-by-step formulation is not what the kernels move; the
                            fraction that still bounds them is the real one.
-  traffic                  HBM bytes per K-step run from rocprofv3 PMC passes (FETCH_SIZE x 2 per the
+  traffic                  HBM bytes per LAUNCH (= per pass; traffic_per_run / passes_per_run, like avg_launch_ms) from rocprofv3 PMC passes (FETCH_SIZE x 2 per the
                            gfx950 correction of MI355X_MICROARCH.md, WRITE_SIZE exact), collected by THIS
                            run in child processes running the same K-step plan on the same launch shapes.
   overfetch                traffic / (one read + one write of every field per pass = 24 B x cells (+4 B per
@@ -493,8 +493,10 @@ def roofline_block(cells, steps, r, traffic):
         t = traffic["run"]
         real = t["bytes"] / (ev * 1e-3) / 1e9
         names = [k["name"] for k in t["kernels"]]
-        out.update(achieved=round(real, 1), frac=round(real / HBM_PEAK_GBS, 4), traffic=t["bytes"],
-                   traffic_source=traffic["source"], traffic_read_write=[t["read"], t["write"]],
+        npass = max(1, traffic["passes_per_run"])
+        out.update(achieved=round(real, 1), frac=round(real / HBM_PEAK_GBS, 4), traffic=int(t["bytes"] / npass),
+                   traffic_per_run=t["bytes"], traffic_source=traffic["source"],
+                   traffic_read_write=[int(t["read"] / npass), int(t["write"] / npass)],
                    overfetch=round(t["bytes"] / (once * max(1, traffic["passes_per_run"])), 3),
                    kernel=" + ".join(names), kernels=t["kernels"])
         if t["valu_insts"]:

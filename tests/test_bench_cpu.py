@@ -36,7 +36,8 @@ def test_roofline_block_of_a_run_and_of_the_full_length_kernel():
     ev = float(np.median(r["events_ms"]))
     assert b["bound"] == "hbm" and b["peak"] == 8000.0 and b["unit"] == "GB/s"
     assert abs(b["achieved"] - 7.3e9 / (ev * 1e-3) / 1e9) < 0.1 and abs(b["frac"] - b["achieved"] / 8000.0) < 1e-3
-    assert b["traffic"] == 7_300_000_000 and abs(b["overfetch"] - 7.3e9 / (cells * 24)) < 1e-3
+    assert b["traffic"] == 7_300_000_000 and b["traffic_per_run"] == 7_300_000_000 and abs(b["overfetch"] - 7.3e9 / (cells * 24)) < 1e-3
+    assert abs(b["avg_launch_ms"] - ev) < 1e-4 and abs(b["traffic"] / (b["avg_launch_ms"] * 1e-3) / 1e9 - b["achieved"]) < 0.5
     assert b["kernel"] == "fdtd::k_zone<float, 20> + fdtd::k_bulk_split<float, 20>" and b["launch_shape"]["pass_steps"] == 20
     assert abs(b["algorithmic"]["x_peak"] - cells * steps * 24 / (ev * 1e-3) / 1e9 / 8000.0) < 1e-2
     ss = b["steady_state"]

@@ -1418,12 +1418,18 @@ int fdtd2d_pass_commit(fdtd2d_t *h)
         return fail(h, FDTD2D_E_STATE, "pending pass covers rows [%d,%d) of the owned [%d,%d): dropped",
                     c_lo, at, own_lo, own_hi);
     }
+    // (a running Fourier transform samples at fixed steps: a pass issued in pieces must end ON the next sampled step or
+    // before it -- fdtd2d_run cuts its passes there by itself, callers of fdtd2d_pass_rows choose nt accordingly)
+    const bool skipped = h->dft_n && h->dft_gap() < nt;
     h->cur ^= 1;
     h->hcur ^= 1;
     h->ev = h->hv = Range{c_lo, at};
     h->step += nt;
     h->pend_nt = 0;
     h->pend_done.clear();
+    if (skipped)
+        return fail(h, FDTD2D_E_STATE, "the %d-step pass ran over a step the running Fourier transform samples (every %d steps)",
+                    nt, h->dft_every);
     return dft_after_step(h);
 }
 

@@ -191,3 +191,23 @@ def test_running_fourier_transform_matches_oracle(tag, dtype, every, max_steps):
         assert np.array_equal(a, b)
     assert got.shape == want.shape and np.abs(want).max() > 0
     assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max(), np.abs(got - want).max() / np.abs(want).max()
+
+
+def test_running_fourier_transform_on_slabs_needs_an_aligned_cycle():
+    """A slab handle whose passes are issued in pieces: a 16-step pass may end on a sampled step (every = 16) but not run
+    over one (every = 10) -- the commit says so instead of silently losing samples; fdtd2d_run_slab refuses up front."""
+    import fdtd2d_amd as fd
+    r, c = 200, 300
+    om = 2 * np.pi * np.array([30e9])
+    with fd.Engine(r, c, 5e-14, 1e-4, dtype=np.float32, slab=(0, 100, 16)) as eng:
+        eng.set_materials().set_option(max_pass_steps=16)
+        eng.set_dft((10, 10, 50, 50), om, 16)
+        eng.pass_rows(16, 0, 100)              # rows [0, 100): the owned rows of this top slab (halo rows stay stale)
+        eng.pass_commit()
+        assert eng.step_count == 16 and np.abs(eng.read_dft()).max() == 0.0      # zero fields: a sample of zeros
+    with fd.Engine(r, c, 5e-14, 1e-4, dtype=np.float32, slab=(0, 100, 16)) as eng:
+        eng.set_materials().set_option(max_pass_steps=16)
+        eng.set_dft((10, 10, 50, 50), om, 10)
+        eng.pass_rows(16, 0, 100)
+        with pytest.raises(fd.Fdtd2dError):
+            eng.pass_commit()

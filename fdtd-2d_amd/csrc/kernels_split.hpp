@@ -393,7 +393,9 @@ __global__ __launch_bounds__(64 * SPLIT_NW * SD) void k_bulk_split(const PassPar
 #endif
     if constexpr (FUSE) {    // zone tiles are the first workgroups of the launch (all NW waves per tile)
         const int nzone = p.zone_wgs;
-        if (b < nzone) {
+        const int bz = p.zone_last ? b - ((int)gridDim.x - nzone) : b;      // index among the zone workgroups (first or last in the launch)
+        if (bz >= 0 && bz < nzone) {
+            b = bz;
             if constexpr (zone_in_registers<T, NT>()) {      // two waves per tile, rows in registers (kernels_zone.hpp)
                 zone_wave_group<T, NT, CE_ARR, CH_ARR, 64 * SPLIT_NW>(p, b, reinterpret_cast<T *>(lds));
             } else {
@@ -403,7 +405,7 @@ __global__ __launch_bounds__(64 * SPLIT_NW * SD) void k_bulk_split(const PassPar
             }
             return;
         }
-        b -= nzone;
+        if (!p.zone_last) b -= nzone;
     }
     int strip, ra, rb;
     if (!strip_of_block(p, b, &strip, &ra, &rb)) return;

@@ -69,6 +69,7 @@ template <class T> struct PassParams {
     int zone_top, zone_bot;    // 1 if this launch owns the grid's top / bottom zone
     int zone_tiles;            // column tiles per zone
     int zone_wgs;              // workgroups of the zone part of a fused launch (register-resident tiles: several per workgroup)
+    int zone_last;             // 1: they are the LAST workgroups of the launch (launches of several rounds: short tasks for the tail)
     int fused_zones;           // 1: the zone tiles are the first workgroups of the k_bulk launch
                                // (one wave each); 0: k_zone runs them on a side stream
     T *trash;                  // >= 3 x 1 KiB of device scratch: where masked-off stores land

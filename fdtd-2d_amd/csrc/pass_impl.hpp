@@ -78,6 +78,14 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
                                ? fdtd::zone_wgs_for<T, NT, fdtd::PASS_THREADS>(zone_tiles_all) : zone_tiles_all;
     const long long zones = zones_fused;
     p.zone_wgs = zones_fused;
+    // Launches of several rounds: the zone workgroups -- short tasks since their tiles live in registers -- go LAST, into the
+    // thinning tail of the launch, instead of holding slots of the first round: 16384^2 1270 -> 1232 us per 16-step pass,
+    // eps + mu arrays 1798 -> 1764 (one process, alternating: profiles/r03_zone_last.txt).  One-round launches keep them
+    // first (their slots are re-used by the filler bands).
+    {
+        const long long slots = 256LL * 16 / std::max(1, nw_now);
+        p.zone_last = zones_fused > 0 && bulk * 100 > slots * 135 ? 1 : 0;
+    }
     p.xcd_map = 0;
     p.main_pad = p.main_per = p.main_tasks = 0;
     const bool xcd = h->xcd_map >= 0 ? h->xcd_map != 0 : h->shape_now.xcd != 0;
@@ -85,7 +93,7 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
         // (the zone tiles ride in front of the bulk when fused: the pad makes the first inner-strip task a multiple
         // of 8 in the index the hardware sees)
         const bool side = zones > 0 && (h->zone_split == 1 || NT > 16 || sd > 1);
-        const long long front = (side ? 0 : zones) + 2LL * p.nbands_e + (long long)p.n_src * p.nbands_s;
+        const long long front = ((side || p.zone_last) ? 0 : zones) + 2LL * p.nbands_e + (long long)p.n_src * p.nbands_s;
         p.xcd_map = 1;
         p.main_tasks = p.nbands * p.n_inner;
         p.main_per = (p.main_tasks + 7) / 8;
@@ -360,6 +368,7 @@ template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, 
     // over the grid for a tail of 3, 5, 6, 7, 9..15 steps instead of one per power of two)
     p.strip_first = 1;
     p.xcd_map = p.main_pad = p.main_per = p.main_tasks = p.n_inner = 0;
+    p.zone_wgs = p.zone_last = 0;
     p.band_rows2 = p.nbands2 = 0;
     p.split_row = band_hi;
     p.src_strip = p.n_src = 0;

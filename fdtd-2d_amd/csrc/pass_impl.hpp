@@ -114,9 +114,7 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
             constexpr bool big_tile = !fdtd::zone_in_registers<T, NT>() && (size_t)D::LDS_ELEMS * sizeof(T) > 65536;
             const bool side = zones > 0 && (h->zone_split == 1 || NT > 16 || sd > 1 || big_tile);
             p.fused_zones = zones > 0 && !side;
-            if (side) {
-                HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
-                HIPCHK(h, hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
+            auto launch_side_zones = [&]() -> int {
                 bool wide = false;
                 if constexpr (NT > 16 && sizeof(T) == 4) {
                     // 128-column LDS tiles (dynamic LDS: 95 KB) on grids of 16384 columns and more (ZoneDims); below that
@@ -148,6 +146,20 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
                 }
                 HIPCHK(h, hipGetLastError());
                 HIPCHK(h, hipEventRecord(h->ev_join, h->side_stream));
+                return 0;
+            };
+            // Register-resident tiles are short tasks: their kernel is enqueued BEHIND the bulk kernel, so that they fill in as
+            // slots free up instead of taking slots of the bulk's first round -- run(20) at 8192^2 0.556 -> 0.505 ms; the
+            // 128-column LDS tiles of wide grids stay in front (16384^2: 1.636 either way; register tiles there 1.68)
+            // (one process, alternating: profiles/r03_zone_last.txt).
+            const bool wide_tiles = NT > 16 && sizeof(T) == 4 && h->cols >= 16384;
+            const bool zones_after = side && fdtd::zone_in_registers<T, NT>() && !wide_tiles;
+            if (side) {
+                HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
+                HIPCHK(h, hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
+            }
+            if (side && !zones_after) {
+                if (int rcz = launch_side_zones()) return rcz;
             }
             const long long blocks = bulk + (p.fused_zones ? zones : 0);
 #ifdef FDTD2D_TRACE
@@ -200,6 +212,9 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
                 }
                 }
                 HIPCHK(h, hipGetLastError());
+            }
+            if (side && zones_after) {
+                if (int rcz = launch_side_zones()) return rcz;
             }
             if (side) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
             h->pass_launches++;

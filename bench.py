@@ -74,7 +74,7 @@ SIMDS, PEAK_GHZ, VALU_ISSUE_CYCLES = 1024, 2.4, 2.0      # 256 CUs x 4 SIMD-32; 
 SLAB_ROWS = 4096
 NP_DTYPE = {"f32": np.float32, "f64": np.float64}
 SHAPE_KEYS = ("band_rows", "waves_per_level_group", "edge_strip_band_rows", "waves_side_by_side", "xcd_map",
-              "filler_band_rows", "filler_bands_per_strip")
+              "filler_band_rows", "filler_bands_per_strip", "zone_tiles_fused")
 ENGINE_OPTS = {}     # --opt name=value: Engine.set_option() knobs for A/B experiments (speed only, same results)
 
 

@@ -151,6 +151,10 @@ struct fdtd2d {
         // the launch and their slots would idle.  The last n_short bands of every inner strip are `short_rows` tall
         // and come last in launch order: they start in the slots the zone tiles free and end with the tall bands.
         int short_rows = 0, n_short = 0;
+        // float32 20-step passes, one wave per level group: zone tiles as workgroups of the bulk launch (1) instead of
+        // k_zone on the side stream (0) -- the tuner measures both (16384^2 run(20) 1.74 -> 1.68 ms, 4096^2 0.222 -> 0.199,
+        // 8192^2 0.508 -> 0.543 with the shapes tuned for the side stream: profiles/r03_zone20_fused.txt)
+        int fuse = 0;
     };
     // strips of several waves side by side exist for the float32 16- and 20-step level-split kernels with 4 waves
     // per level group, on grids wide enough for a few of them

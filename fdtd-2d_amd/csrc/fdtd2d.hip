@@ -1242,6 +1242,15 @@ static int tune_pass(fdtd2d *h, int nt, int lo, int hi, bool zt, bool zb, int sr
                 fin.push_back(t);
                 fin_ms.push_back(fin_ms[k]);
             }
+        // 20-step float32 passes: every finalist of one wave per level group again with its zone tiles in the bulk launch
+        if (nt > 16 && h->dtype == FDTD2D_F32 && split)
+            for (size_t k = 0, n = fin.size(); k < n; ++k) {
+                if (fin[k].side > 1) continue;
+                fdtd2d::Shape t = fin[k];
+                t.fuse = 1;
+                fin.push_back(t);
+                fin_ms.push_back(fin_ms[k]);
+            }
         cand = fin;
         best_of = fin_ms;
         order.resize(cand.size());
@@ -1255,9 +1264,9 @@ static int tune_pass(fdtd2d *h, int nt, int lo, int hi, bool zt, bool zb, int sr
             float ms = 0;
             if ((rc = timed(cand[order[k]], 6, &ms))) break;
 #ifdef FDTD2D_TUNE_LOG      // profiling builds only (tools/): what the tuner saw
-            fprintf(stderr, "tune nt=%d final %d: (%d, %d, %d, side %d, xcd %d, filler %d x %d) first rounds %.4f ms, now %.4f ms\n", nt, round,
+            fprintf(stderr, "tune nt=%d final %d: (%d, %d, %d, side %d, xcd %d, filler %d x %d, fuse %d) first rounds %.4f ms, now %.4f ms\n", nt, round,
                     cand[order[k]].band_rows, cand[order[k]].waves, cand[order[k]].edge_rows, cand[order[k]].side,
-                    cand[order[k]].xcd, cand[order[k]].short_rows, cand[order[k]].n_short, best_of[order[k]], ms);
+                    cand[order[k]].xcd, cand[order[k]].short_rows, cand[order[k]].n_short, cand[order[k]].fuse, best_of[order[k]], ms);
 #endif
             // (8 waves per strip run 5-7 % slower on a run's real fields than in these trials on the fields at
             // hand -- zero in a fresh engine: 8192^2 ring map 0.53 ms in trials, 0.57 ms in the run, while the
@@ -1511,13 +1520,15 @@ int fdtd2d_set_option(fdtd2d_t *h, int option, long long value)
 int fdtd2d_set_shape(fdtd2d_t *h, int pass_steps, const int *shape, int n)
 {
     if (!h || !shape || n < 1) return FDTD2D_E_ARG;
-    int v[FDTD2D_SHAPE_LEN] = {0, 0, 0, 1, 0, 0, 0};
+    int v[FDTD2D_SHAPE_LEN] = {0, 0, 0, 1, 0, 0, 0, 0};
     for (int k = 0; k < n && k < FDTD2D_SHAPE_LEN; ++k) v[k] = shape[k];
     if (v[3] == 0) v[3] = 1;
     if (pass_steps < 0 || pass_steps > fdtd::STREAM_MAX_NT || v[0] < 0 || (v[1] != 0 && v[1] != 4 && v[1] != 8) || v[2] < 0 ||
-        (v[3] != 1 && v[3] != 2 && v[3] != 4) || (v[4] != 0 && v[4] != 1) || v[5] < 0 || v[6] < 0)
-        return fail(h, FDTD2D_E_ARG, "shape = {band rows, waves 0|4|8, edge band rows, side 1|2|4, xcd 0|1, filler rows, fillers per strip}");
-    h->given_shape[pass_steps] = fdtd2d::Shape{v[0], v[1], v[2], v[3], v[4], v[5], v[6]};
+        (v[3] != 1 && v[3] != 2 && v[3] != 4) || (v[4] != 0 && v[4] != 1) || v[5] < 0 || v[6] < 0 ||
+        (v[7] != 0 && v[7] != 1))
+        return fail(h, FDTD2D_E_ARG, "shape = {band rows, waves 0|4|8, edge band rows, side 1|2|4, xcd 0|1, filler rows, fillers per strip, "
+                                     "zone tiles fused 0|1}");
+    h->given_shape[pass_steps] = fdtd2d::Shape{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
     return 0;
 }
 
@@ -1525,7 +1536,7 @@ int fdtd2d_last_shape(const fdtd2d_t *h, int *shape, int n)
 {
     if (!h || !shape || n < 1) return FDTD2D_E_ARG;
     const fdtd2d::Shape &s = h->shape_last;
-    const int v[FDTD2D_SHAPE_LEN] = {s.band_rows, s.waves, s.edge_rows, s.side, s.xcd, s.short_rows, s.n_short};
+    const int v[FDTD2D_SHAPE_LEN] = {s.band_rows, s.waves, s.edge_rows, s.side, s.xcd, s.short_rows, s.n_short, s.fuse};
     for (int k = 0; k < n; ++k) shape[k] = k < FDTD2D_SHAPE_LEN ? v[k] : 0;
     return 0;
 }

@@ -69,6 +69,9 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
     }
     long long bulk = 2LL * p.nbands_e + (long long)p.n_src * p.nbands_s +
                      (long long)(p.nbands + p.nbands2) * p.n_inner;
+    // 20-step passes (float32, one wave per level group): the register-resident zone tiles may ride in the bulk launch too
+    // (Shape::fuse, the tuner's choice)
+    const bool fuse_long = NT > 16 && sizeof(T) == 4 && sd == 1 && h->shape_now.fuse != 0;
     const int zone_tiles_all = (p.zone_top + p.zone_bot) * p.zone_tiles;
     // workgroups of the zone tiles: in the fused launch (64 x waves-per-strip threads) and as k_zone (256 threads)
     const int nw_now = NT >= 8 && h->use_level_split(NT, p.band_lo, p.band_hi) ? h->split_waves_for(NT, p.band_lo, p.band_hi) : 1;
@@ -92,7 +95,7 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
     if (xcd && NT >= 8 && h->use_level_split(NT, p.band_lo, p.band_hi) && p.nstrips - 2 - p.n_src > 0) {
         // (the zone tiles ride in front of the bulk when fused: the pad makes the first inner-strip task a multiple
         // of 8 in the index the hardware sees)
-        const bool side = zones > 0 && (h->zone_split == 1 || NT > 16 || sd > 1);
+        const bool side = zones > 0 && (h->zone_split == 1 || (NT > 16 && !fuse_long) || sd > 1);
         const long long front = ((side || p.zone_last) ? 0 : zones) + 2LL * p.nbands_e + (long long)p.n_src * p.nbands_s;
         p.xcd_map = 1;
         p.main_tasks = p.nbands * p.n_inner;
@@ -112,7 +115,7 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
             // (an LDS tile that does not fit a static allocation would have to run as k_zone with dynamic LDS, never fused:
             // float64 16-step passes until their tiles moved into the registers of four waves)
             constexpr bool big_tile = !fdtd::zone_in_registers<T, NT>() && (size_t)D::LDS_ELEMS * sizeof(T) > 65536;
-            const bool side = zones > 0 && (h->zone_split == 1 || NT > 16 || sd > 1 || big_tile);
+            const bool side = zones > 0 && (h->zone_split == 1 || (NT > 16 && !fuse_long) || sd > 1 || big_tile);
             p.fused_zones = zones > 0 && !side;
             auto launch_side_zones = [&]() -> int {
                 bool wide = false;
@@ -192,6 +195,10 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
                     }
                 } else if constexpr (NT > 16) {
                     // 20 steps: 4 waves x 5 levels, zone tiles on the side stream
+                    if constexpr (sizeof(T) == 4) {
+                        if (p.fused_zones) hipLaunchKernelGGL((fdtd::k_bulk_split<T, NT, 4, true, CE_ARR, CH_ARR, V>), grid, wg, 0, h->stream, p);
+                        else hipLaunchKernelGGL((fdtd::k_bulk_split<T, NT, 4, false, CE_ARR, CH_ARR, V>), grid, wg, 0, h->stream, p);
+                    } else
                     hipLaunchKernelGGL((fdtd::k_bulk_split<T, NT, 4, false, CE_ARR, CH_ARR, V>), grid, wg, 0, h->stream, p);
                 } else {
                 const bool w8 = nw == 8;
@@ -370,7 +377,8 @@ template <class T> int launch_pass(fdtd2d *h, int nt, int band_lo, int band_hi, 
                                   h->pml_split(nt) ? 4 : (h->use_level_split(nt, band_lo, band_hi) ? h->split_waves_for(nt, band_lo, band_hi) : 1),
                                   h->pml_split(nt) ? (h->shape_now.edge_rows > 0 ? h->shape_now.edge_rows : h->pml_layer_rows) : p.band_rows_e,
                                   h->shape_now.side, h->xcd_map >= 0 ? h->xcd_map : h->shape_now.xcd,
-                                  h->shape_now.short_rows, h->shape_now.n_short};
+                                  h->shape_now.short_rows, h->shape_now.n_short,
+                                  nt > 16 && h->dtype == FDTD2D_F32 && h->shape_now.side <= 1 ? h->shape_now.fuse : 0};
     p.zone_top = ztop;
     p.zone_bot = zbot;
     p.trash = (T *)h->trash;

@@ -337,7 +337,8 @@ class Engine:
 
     def set_shape(self, shape, pass_steps=0):
         """Launch shape of the passes of `pass_steps` steps (0 = the full-length ones): (band rows, waves per level
-        group, edge band rows, waves side by side, xcd map, filler band rows, filler bands per strip) -- what
+        group, edge band rows, waves side by side, xcd map, filler band rows, filler bands per strip, zone tiles of a
+        float32 20-step pass fused 0 | 1) -- what
         last_shape returns, e.g. from another process.  Results do not depend on it."""
         v = [int(x) for x in shape]
         arr = (C.c_int * len(v))(*v)
@@ -475,9 +476,9 @@ class Engine:
     @property
     def last_shape(self):
         """(band rows, waves per level group, band rows of the first / last strip, waves side by side, xcd map, filler
-        band rows, filler bands per strip) of the last pass."""
-        out = (C.c_int * 7)()
-        self._ck(self._lib.fdtd2d_last_shape(self._h, out, 7))
+        band rows, filler bands per strip, zone tiles of a 20-step pass fused into the bulk launch) of the last pass."""
+        out = (C.c_int * 8)()
+        self._ck(self._lib.fdtd2d_last_shape(self._h, out, 8))
         return tuple(int(v) for v in out)
 
     @property

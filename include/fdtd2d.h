@@ -260,10 +260,11 @@ int fdtd2d_set_option(fdtd2d_t *h, int option, long long value);
  * a shape the tuner found elsewhere (another process, an earlier run).  shape[0..n): band rows, waves per level group
  * (0 = automatic, 4, 8), band rows of the first / last strip (0 = the same), waves side by side per level group (1, 2,
  * 4), xcd map (0 / 1), and for launches that fit the GPU in one round: rows and number per strip of the shorter "filler"
- * bands that take over the slots the zone tiles free (0, 0 = none); missing trailing entries are 0 (side: 1);
+ * bands that take over the slots the zone tiles free (0, 0 = none), and for float32 20-step passes whether the zone tiles
+ * ride in the bulk launch (1) or run as their own kernel on a side stream (0); missing trailing entries are 0 (side: 1);
  * shape[0] = 0 clears it.  fdtd2d_last_shape returns the shape the last pass ran with, in the same order.  Results never
  * depend on the shape. */
-#define FDTD2D_SHAPE_LEN 7
+#define FDTD2D_SHAPE_LEN 8
 int fdtd2d_set_shape(fdtd2d_t *h, int pass_steps, const int *shape, int n);
 int fdtd2d_last_shape(const fdtd2d_t *h, int *shape, int n);
 

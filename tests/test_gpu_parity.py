@@ -896,6 +896,34 @@ def test_strips_of_several_waves_side_by_side_match_oracle(fd, onp, side, shape,
         assert np.array_equal(a, b), f"{k} side={side} {kind}: {np.argwhere(a != b)[:4]}"
 
 
+@pytest.mark.parametrize("kind", ["uniform", "eps", "eps+mu"])
+@pytest.mark.parametrize("shape,band,src", [((150, 4200), 40, (24, 251)), ((131, 4096), 64, (130, 4095)), ((600, 16500), 20, (0, 0)),
+                                            ((300, 700), 300, (150, 215))])
+@pytest.mark.parametrize("xcd", [0, 1])
+def test_20_step_pass_with_fused_zone_tiles_matches_oracle(fd, onp, shape, band, src, kind, xcd):
+    """Launch shape entry 7 (fdtd2d_set_shape): the zone tiles of a float32 20-step pass as workgroups of the bulk launch
+    (k_bulk_split<20, 4, FUSE>: register-resident tiles, first in a one-round launch, last in a launch of several rounds --
+    600 x 16500 with 20-row bands is 2300 tasks) instead of k_zone on the side stream.  36 steps = a 16-step pass + a
+    20-step pass from a random state, both task orders; value-identical to the oracle."""
+    r, c = shape
+    rng = np.random.default_rng(r * c + 7)
+    Ez, Hx, Hy, eps, mu = _random_state(rng, r, c, np.float32, onp, vary_mu=(kind == "eps+mu"))
+    if kind == "uniform":
+        eps = np.full((r, c), 2.3 * onp.EPS0, np.float32)
+    n = 36
+    amps = rng.standard_normal(n)
+    ref = [a.copy() for a in (Ez, Hx, Hy)]
+    onp.leapfrog(*ref, eps, mu, DT, DX, n, src[0], src[1], amps=amps)
+    with fd.Engine(r, c, DT, DX, dtype=np.float32) as eng:
+        eng.set_materials(eps, mu).set_option(max_pass_steps=20).set_shape((band, 4, 0, 1, xcd, 0, 0, 1), 20)
+        eng.upload(Ez, Hx, Hy)
+        eng.run(n, src[0], src[1], amps)
+        got = eng.download()
+        assert eng.info(16) == 2 and eng.last_pass_steps == 20 and eng.last_shape[7] == 1 and eng.last_shape[4] == xcd
+    for a, b, k in zip(got, ref, ("Ez", "Hx", "Hy")):
+        assert np.array_equal(a, b), f"{k} {shape} {kind}: {np.argwhere(a != b)[:4]}"
+
+
 @pytest.mark.parametrize("shape,steps", [((60, 4, 0, 1, 0, 40, 2), 0), ((100, 8, 50, 1, 0, 24, 3), 0), ((48, 4, 24, 1, 0, 16, 5), 0),
                                          ((64, 0, 0, 1, 0, 32, 2), 8)])
 @pytest.mark.parametrize("kind", ["uniform", "eps+mu"])
@@ -920,7 +948,7 @@ def test_filler_bands_match_oracle(fd, onp, shape, steps, kind):
         eng.upload(Ez, Hx, Hy)
         eng.run(n, src[0], src[1], amps)
         got = eng.download()
-        assert eng.last_shape[5:] == shape[5:] and eng.last_shape[0] == shape[0]
+        assert eng.last_shape[5:7] == shape[5:7] and eng.last_shape[0] == shape[0]
     for a, b, k in zip(got, ref, ("Ez", "Hx", "Hy")):
         assert np.array_equal(a, b), f"{k} {shape} {kind}: {np.argwhere(a != b)[:4]}"
 

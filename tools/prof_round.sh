@@ -15,7 +15,7 @@ cat $out/bench_summary.txt
 shapes=$(python3 - $out/bench_default.json <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))["roofline"]
-keys = ("band_rows", "waves_per_level_group", "edge_strip_band_rows", "waves_side_by_side", "xcd_map", "filler_band_rows", "filler_bands_per_strip")
+keys = ("band_rows", "waves_per_level_group", "edge_strip_band_rows", "waves_side_by_side", "xcd_map", "filler_band_rows", "filler_bands_per_strip", "zone_tiles_fused")
 for s in (d["launch_shape"], dict(d["steady_state"]["launch_shape"], pass_steps=d["steady_state"]["steps_per_launch"])):
     print("--shape", ":".join(str(int(s[k])) for k in ("pass_steps",) + keys), end=" ")
 PY

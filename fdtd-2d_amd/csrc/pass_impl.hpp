@@ -110,8 +110,9 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
             // launch and two cross-stream event waits per pass -- 38 vs 84 us per 8 steps at
             // 2048^2, 96 vs 99 at 4096^2, equal at 16384^2: profiles/r01_zone_fuse_split.txt) or
             // k_zone on the side stream (zone_split = 1)
-            // (20-step passes: 4 waves x 5 levels at 4 workgroups per CU; a fused 46-row zone tile would
-            // take 48 KB of LDS from every workgroup and leave 3, so their zones always run as k_zone)
+            // (20-step passes: 4 waves x 5 levels at 4 workgroups per CU; a fused 46-row LDS zone tile would
+            // take 48 KB of LDS from every workgroup and leave 3, so their zones ran as k_zone only -- until the
+            // register-resident tiles: float32 launches of one wave per level group may now fuse them, fuse_long)
             // (an LDS tile that does not fit a static allocation would have to run as k_zone with dynamic LDS, never fused:
             // float64 16-step passes until their tiles moved into the registers of four waves)
             constexpr bool big_tile = !fdtd::zone_in_registers<T, NT>() && (size_t)D::LDS_ELEMS * sizeof(T) > 65536;
@@ -194,12 +195,15 @@ int launch_pass_impl(fdtd2d *h, fdtd::PassParams<T> &p)
                         return fail(h, FDTD2D_E_ARG, "strips of several waves side by side: 16-step passes and float32 20-step passes only");
                     }
                 } else if constexpr (NT > 16) {
-                    // 20 steps: 4 waves x 5 levels, zone tiles on the side stream
+                    // 20 steps: 4 waves x 5 levels; zone tiles on the side stream or (float32, Shape::fuse) in this launch
+                    bool launched = false;
                     if constexpr (sizeof(T) == 4) {
-                        if (p.fused_zones) hipLaunchKernelGGL((fdtd::k_bulk_split<T, NT, 4, true, CE_ARR, CH_ARR, V>), grid, wg, 0, h->stream, p);
-                        else hipLaunchKernelGGL((fdtd::k_bulk_split<T, NT, 4, false, CE_ARR, CH_ARR, V>), grid, wg, 0, h->stream, p);
-                    } else
-                    hipLaunchKernelGGL((fdtd::k_bulk_split<T, NT, 4, false, CE_ARR, CH_ARR, V>), grid, wg, 0, h->stream, p);
+                        if (p.fused_zones) {
+                            hipLaunchKernelGGL((fdtd::k_bulk_split<T, NT, 4, true, CE_ARR, CH_ARR, V>), grid, wg, 0, h->stream, p);
+                            launched = true;
+                        }
+                    }
+                    if (!launched) hipLaunchKernelGGL((fdtd::k_bulk_split<T, NT, 4, false, CE_ARR, CH_ARR, V>), grid, wg, 0, h->stream, p);
                 } else {
                 const bool w8 = nw == 8;
                 // (a piece without zone tiles can run on either build; 8-step passes over array

@@ -249,6 +249,27 @@ def make_materials(fd, kind, rows, cols, r0=0, r1=None, dtype=np.float32):
     raise ValueError(kind)
 
 
+CLOCK_WARMUP_MS = 30.0
+
+
+def clock_warmup(eng, cyc=0, target_ms=CLOCK_WARMUP_MS):
+    """Untimed, right before a timed region: keep the GPU busy for ~30 ms.  An idle chip needs 10-20 ms of work before it
+    holds its clock (the repetitions of a 1.7 ms run kept getting shorter from the 2nd to the 11th, and the set-up steps
+    before them -- an amdsmi sample, a barrier -- are idle gaps; profiles/r03_clock_vs_launch.txt).  With cyc > 0: full-length
+    passes on the engine's own fields (a whole-grid engine: the synthetic state simply moves on); else the library's copy
+    kernel, which leaves the state alone (slab engines, whose halos a pass without an exchange would invalidate).  Returns
+    the milliseconds spent."""
+    t0 = time.perf_counter()
+    for _ in range(64):
+        if (time.perf_counter() - t0) * 1e3 >= target_ms:
+            break
+        if cyc > 0:
+            eng.time_launches(8, cyc)
+        else:
+            eng.measure_copy(8)
+    return round((time.perf_counter() - t0) * 1e3, 1)
+
+
 def make_engine(fd, rows, cols, materials, device, boundary, shapes=None, autotune=True, dtype=np.float32):
     eng = fd.Engine(rows, cols, DT, DX, dtype=dtype, device=device, boundary=boundary)
     eps, mu = make_materials(fd, materials, rows, cols, dtype=dtype)
@@ -281,9 +302,10 @@ def time_single(fd, rows, cols, steps, warmup, materials, device, boundary="mur"
     cyc = eng.cycle_steps
     copy = [eng.measure_copy(4)]        # what a plain copy of the same arrays reaches on this device right now
     walls, events, first = [], [], warmup
-    l0 = eng.info(16), eng.info(17)
     if gpu is not None:
         gpu.sample()
+    warm_ms = clock_warmup(eng, cyc)
+    l0 = eng.info(16), eng.info(17)
     for _ in range(repeats):
         amps = amplitudes(fd, first, steps)
         first += steps
@@ -298,7 +320,7 @@ def time_single(fd, rows, cols, steps, warmup, materials, device, boundary="mur"
         events.append(ev_ms)
     res = dict(walls=walls, events_ms=events, pass_launches=(eng.info(16) - l0[0]) // repeats,
                step_launches=(eng.info(17) - l0[1]) // repeats, bpc=eng.bytes_per_cell_step, launch_steps=cyc,
-               run_shape=list(eng.last_shape), run_last_nt=eng.last_pass_steps)
+               run_shape=list(eng.last_shape), run_last_nt=eng.last_pass_steps, clock_warmup_ms=warm_ms)
     # duration of the full-length pass kernel by itself: single launches, each between its own pair of HIP
     # events on the engine's stream (what rocprofv3's kernel trace reports)
     if cyc:
@@ -537,6 +559,9 @@ def single_record(fd, rows, cols, steps, warmup, materials, boundary, device, pm
            "warmup": warmup, "ms_per_step": round(wall * 1e3 / steps, 5), "repeats": repeats,
            "value_min_max": [round(cells * steps / max(r["walls"]) / 1e6, 1), round(cells * steps / min(r["walls"]) / 1e6, 1)],
            "wall_ms_all": [round(w * 1e3, 4) for w in r["walls"]], "dtype": dtype,
+           "clock_warmup": {"ms": r["clock_warmup_ms"],
+                            "how": "untimed full-length passes right before the timed repetitions, after the W warm-up steps and "
+                                   "the set-up around them: the chip needs 10-20 ms of work to hold its clock"},
            "config": {"workload": f"{rows}x{cols} {'fp32' if dtype == 'f32' else 'fp64'} TE-mode, {materials} eps/mu, "
                                   + ("Mur-5" if boundary == "mur" else "split-field PML (40 cells)")
                                   + " boundary, ricker point source at the centre" + note,
@@ -733,7 +758,7 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
                "data": "synthetic", "config": head["config"], "repeats": head["repeats"],
                "value_min_max": head["value_min_max"], "wall_ms_all": head["wall_ms_all"],
-               "roofline": head["roofline"],
+               "clock_warmup": head["clock_warmup"], "roofline": head["roofline"],
                "gpu_state": {"source": "amdsmi gpu_metrics", "partition": getattr(gpu, "partition", None),
                              "device": getattr(gpu, "device", None),
                              "before": before, "during_timed_region": head.get("gpu_during"), "after": gpu.read()}}
@@ -782,6 +807,11 @@ def main():
         runner.prepare(args.steps)      # kernels of the last, shorter cycle: part of set-up
         if gpu is not None:
             gpu.sample()
+        torch.cuda.synchronize()
+        dist.barrier()
+        # every rank keeps its GPU busy for ~30 ms (copy kernel: the slab's state and halos stay as they are) so that the
+        # timed cycles run at the clock a long run holds, like the N = 1 line's repetitions
+        warm_ms = clock_warmup(runner.engine)
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
@@ -855,6 +885,8 @@ def main():
                        "rccl_rank_of_ranks": list(ranks_seen) if ranks_seen else None,
                        "torch_world_size": dist.get_world_size(),
                        "host_us_per_cycle": round(host_s * 1e6 / ncyc, 1)},
+            "clock_warmup": {"ms": warm_ms, "how": "untimed copy-kernel launches on every rank between two barriers right "
+                                                   "before the timed region (state untouched)"},
             "verification": verify,
             "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                          "frac": None, "traffic": None,
